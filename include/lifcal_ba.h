@@ -1,0 +1,221 @@
+/*
+ * lifcal_ba.h — C ABI of the MI355X-native plenoptic bundle-adjustment solver.
+ *
+ * Drop-in boundary: the body of LiFCal's CameraCalibration::performBundleAdjustment()
+ * (reference src/CameraCalibration.cpp:774-992), i.e. everything between
+ * "ceres::Problem minimizationProblem" (:858) and "ceres::Solve" (:965), plus
+ * calcReprojectionError() (:1026-1103).  The reference has no FFI of its own; these entry
+ * points are what a binding for that seam would call (see INTEGRATION.md for the adapter).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - All parameter arrays are owned by the caller; lifcal_ba_solve() updates them IN PLACE on
+ *     return (Ceres semantics: reference :892-911 registers the caller's own storage).
+ *   - Every function returns 0 on success or a negative lifcal_ba_status; nothing throws.
+ *   - A handle is not re-entrant; one host thread drives it.
+ *   - There is NO CPU fallback: without a usable gfx950 device create() fails with
+ *     LIFCAL_BA_ERR_NO_DEVICE.
+ */
+#ifndef LIFCAL_BA_H
+#define LIFCAL_BA_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* reference: #define MAX_NUMBER_OF_CAMERA_PARAMETERS 17  (src/CalibrationData/CalibrationData.h:19) */
+#define LIFCAL_BA_MAX_CAMERA_PARAMETERS 17
+
+/* config bitmask — identical bit layout to reference src/CameraCalibration.cpp:778-814 and the
+ * decoder in src/BundleAdjustment/BundleAdjustment.h:28-79 */
+#define LIFCAL_BA_CFG_NRADIAL_MASK   0x000003u  /* number of radial coefficients (0..2)           */
+#define LIFCAL_BA_CFG_TANGENTIAL     0x000004u  /* two tangential coefficients                    */
+#define LIFCAL_BA_CFG_REFINE_POSES   0x000100u  /* Model.refineExtrinsicOrientations              */
+#define LIFCAL_BA_CFG_ROBUST         0x000200u  /* Model.robustCostFunction -> CauchyLoss(0.5)    */
+#define LIFCAL_BA_CFG_REFINE_POINTS  0x000400u  /* Model.refineCoordinatesPoints                  */
+#define LIFCAL_BA_CFG_ML_CENTER_ADJ  0x000800u  /* Model.adjustMicroLensCenters                   */
+
+typedef enum {
+  LIFCAL_BA_OK               =  0,
+  LIFCAL_BA_ERR_INVALID_ARG  = -1,
+  LIFCAL_BA_ERR_NO_DEVICE    = -2,  /* no gfx950 device / HIP runtime failure at create        */
+  LIFCAL_BA_ERR_HIP          = -3,  /* a HIP call failed later (see lifcal_ba_last_error)      */
+  LIFCAL_BA_ERR_OUT_OF_RANGE = -4,  /* an index in pt/fr/c_i/c_j exceeds n_points/n_frames     */
+  LIFCAL_BA_ERR_NOMEM        = -5,
+  LIFCAL_BA_ERR_COMM         = -6,  /* all-reduce hook / RCCL failure                           */
+  LIFCAL_BA_ERR_NUMERIC      = -7   /* non-finite cost at the initial point                     */
+} lifcal_ba_status;
+
+/* termination reasons of lifcal_ba_solve (Ceres 2.1 TrustRegionMinimizer vocabulary) */
+typedef enum {
+  LIFCAL_BA_TERM_NONE               = 0,
+  LIFCAL_BA_TERM_FUNCTION_TOLERANCE = 1,  /* |dcost| <= f_tol * cost                           */
+  LIFCAL_BA_TERM_PARAMETER_TOLERANCE= 2,  /* |step| <= p_tol (|x| + p_tol)                     */
+  LIFCAL_BA_TERM_GRADIENT_TOLERANCE = 3,  /* max|g| <= g_tol                                    */
+  LIFCAL_BA_TERM_MAX_ITERATIONS     = 4,
+  LIFCAL_BA_TERM_MIN_RADIUS         = 5,  /* trust-region radius below 1e-32                    */
+  LIFCAL_BA_TERM_INVALID_STEPS      = 6   /* 5 consecutive invalid steps (Cholesky failed ...)  */
+} lifcal_ba_termination;
+
+/*
+ * The problem, flattened from the reference's host structures:
+ *   cam    <- double camera[17] = {fL, bL0, B, cx, cy, k_1..k_nRad, p_1, p_2, 0...}   (:821-853)
+ *   views  <- double views[6F], per frame {ax, ay, az, tx, ty, tz}, Euler XYZ          (:864-868)
+ *   pts    <- std::vector<Eigen::Vector3d> p3d_w, contiguous 24-byte records           (CameraCalibration.h:102)
+ *   u,v    <- frame::rawImageCoordinates[k]           (CalibrationData.h:40)
+ *   mcx,mcy<- frame::microLensCenter[k]               (CalibrationData.h:41)
+ *   pt     <- frame::objectCoordinatesByRawID[k] - p3d_w.data()   (CalibrationData.h:42)
+ *   fr     <- index of the frame the observation belongs to
+ *   spx,spy<- pixelSize_totFoc (both), scale <- (double)depth_to_raw_im_scale          (:882)
+ *   c_*    <- std::vector<Constraint>{pointID_1, pointID_2, distance, sigma}; they are used only
+ *             when REFINE_POINTS is set and use_constraints != 0 (reference :916: not in recalib)
+ *   fixed_mask / lower / upper <- recalib: SubsetManifold(17,{0,2}) and box bounds (:927-953).
+ *             lower/upper may be NULL (unbounded); otherwise 17 entries, +-INFINITY = unbounded.
+ * Observations may be given in any order (the reference's is frame-major); the library re-sorts
+ * internally and never returns per-observation data in its own order.
+ */
+typedef struct lifcal_ba_problem {
+  uint32_t n_obs, n_frames, n_points, n_constraints;
+  const double*   u;
+  const double*   v;
+  const double*   mcx;
+  const double*   mcy;
+  const uint32_t* pt;
+  const uint32_t* fr;
+  double* cam;    /* [17]  in/out */
+  double* views;  /* [6F]  in/out */
+  double* pts;    /* [3P]  in/out */
+  double spx, spy, scale;
+  uint32_t config;
+  uint32_t fixed_mask;       /* bit i set -> camera[i] held constant */
+  const double* lower;       /* [17] or NULL */
+  const double* upper;       /* [17] or NULL */
+  const uint32_t* c_i;       /* [M] or NULL */
+  const uint32_t* c_j;
+  const double*   c_dist;
+  const double*   c_sigma;
+  uint32_t use_constraints;  /* 0: ignore c_* (recalib), 1: add them when REFINE_POINTS */
+  uint32_t reserved;
+} lifcal_ba_problem;
+
+/* Solver options; defaults = what the reference hard-codes (:955-961) + Ceres 2.1 defaults. */
+typedef struct lifcal_ba_options {
+  double function_tolerance;    /* 1e-6  (:958) */
+  double parameter_tolerance;   /* 1e-8  (:959) */
+  double gradient_tolerance;    /* 1e-10 (Ceres default) */
+  double initial_radius;        /* 1e4   (Ceres default initial_trust_region_radius) */
+  double max_radius;            /* 1e16 */
+  double min_radius;            /* 1e-32 */
+  double min_relative_decrease; /* 1e-3 */
+  double min_lm_diagonal;       /* 1e-6 */
+  double max_lm_diagonal;       /* 1e32 */
+  double loss_scale;            /* 0.5: CauchyLoss(0.5) (:892) */
+  int32_t max_iterations;       /* 200 (:960) */
+  int32_t jacobi_scaling;       /* 1 */
+  int32_t precision;            /* 0: fp64 everywhere; 1: fp32 residual/Jacobian, fp64 accumulation */
+  int32_t device;               /* HIP device ordinal */
+  int32_t rank;                 /* this process' rank in the point-sharded job (0 if single GPU) */
+  int32_t world_size;           /* number of ranks (1 if single GPU) */
+  int32_t verbose;              /* 1: print Ceres-style per-iteration table to stdout (:957) */
+  int32_t deterministic;        /* 1: ordered slab reduction instead of f64 atomics where offered */
+} lifcal_ba_options;
+
+typedef struct lifcal_ba_summary {
+  double initial_cost, final_cost;
+  double final_radius;
+  double final_gradient_max_norm;
+  int32_t iterations;             /* LM iterations taken (Ceres counts iteration 0 separately) */
+  int32_t successful_steps, unsuccessful_steps;
+  int32_t termination;            /* lifcal_ba_termination */
+  double seconds_total, seconds_sweep, seconds_linear_solve;
+} lifcal_ba_summary;
+
+/* One Jacobian+Schur sweep (the benchmarked unit).  Host pointers may be NULL to
+ * skip the copy-back.  Canonical reduced ordering of S/rhs: [camera 0..16 | views 6F | promoted
+ * points 3 each, in ascending point id]; fixed / structurally-dead camera slots are returned as
+ * identity rows with rhs 0.  S is row-major n_red x n_red, symmetric, both triangles filled. */
+typedef struct lifcal_ba_sweep_out {
+  double cost;                   /* 1/2 sum rho(|r|^2) (+ constraints) at the current point      */
+  double gradient_max_norm;      /* max |J^T r| over all free parameters                          */
+  uint32_t n_reduced;            /* 17 + 6F + 3*n_promoted                                        */
+  uint32_t n_promoted;
+  double* S;                     /* [n_reduced^2] or NULL                                         */
+  double* rhs;                   /* [n_reduced]   or NULL:  S * delta_reduced = rhs               */
+  double* gradient_reduced;      /* [n_reduced]   or NULL:  J_B^T r before elimination            */
+  double* point_gradient;        /* [3P]          or NULL:  J_P^T r                               */
+  double* point_hessian_inv;     /* [9P]          or NULL:  (U_p + D_p)^-1 row-major              */
+  double seconds;                /* device time of the sweep kernels (HIP events)                 */
+} lifcal_ba_sweep_out;
+
+/* reference calcReprojectionError (:1026-1103) */
+typedef struct lifcal_ba_stats {
+  double std_x, std_y;   /* sqrt(sum e^2 / N): RMS, not mean-removed (:1097-1098) */
+  double mae_x, mae_y;   /* MAX abs error despite the name (:1083-1084)           */
+  uint32_t num_points, num_inliers;   /* |e|^2 <= thr^2 (:1088)                   */
+} lifcal_ba_stats;
+
+typedef struct lifcal_ba_handle lifcal_ba_handle;
+
+/* Multi-GPU: observations are sharded by 3D point across ranks (one process per GPU).  The only
+ * data-path exchange is a sum all-reduce of f64 device buffers.  Either install a hook (the host
+ * language supplies the collective, e.g. torch.distributed -> RCCL) or let the library own an
+ * RCCL communicator (lifcal_ba_comm_init_rccl).  `stream` is the hipStream_t the buffer was
+ * produced on; the hook must leave the reduced result in place, ordered on that stream. */
+typedef int (*lifcal_ba_allreduce_fn)(void* ctx, void* device_buf, size_t count_f64, void* stream);
+
+void lifcal_ba_default_options(lifcal_ba_options* o);
+
+/* replaces reference :858-953 (problem construction): validates, sorts observations point-major,
+ * builds the tile layout and uploads everything to HBM. */
+int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lifcal_ba_handle** out);
+
+/* replaces reference :965 (ceres::Solve) + :967-988 is the caller's unpack of cam[] */
+int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s);
+
+/* one Jacobian+Schur sweep at trust-region radius `radius` on the CURRENT device-resident point */
+int lifcal_ba_sweep(lifcal_ba_handle* h, double radius, lifcal_ba_sweep_out* out);
+
+/* replaces reference :1026-1103 (evaluated on the device-resident parameters) */
+int lifcal_ba_reproj_stats(lifcal_ba_handle* h, double inlier_threshold, lifcal_ba_stats* out);
+
+/* re-upload cam/views/pts from the caller's arrays (e.g. to re-run from a new initial point) */
+int lifcal_ba_upload_parameters(lifcal_ba_handle* h);
+/* copy the device-resident cam/views/pts back into the caller's arrays */
+int lifcal_ba_download_parameters(lifcal_ba_handle* h);
+
+int lifcal_ba_set_allreduce(lifcal_ba_handle* h, lifcal_ba_allreduce_fn fn, void* ctx);
+/* RCCL path: rank 0 calls unique_id (128 bytes), distributes it, every rank calls init */
+int lifcal_ba_comm_unique_id(void* out128);
+int lifcal_ba_comm_init_rccl(lifcal_ba_handle* h, const void* unique_id128);
+
+/* introspection used by bench.py / tests */
+typedef struct lifcal_ba_info {
+  uint32_t n_obs_local, n_points_local, n_groups, n_tiles, n_lenses, n_reduced, n_promoted;
+  uint32_t n_chunks, max_window_frames;
+  uint64_t device_bytes;
+  void* stream;          /* hipStream_t all kernels are launched on */
+} lifcal_ba_info;
+int lifcal_ba_get_info(lifcal_ba_handle* h, lifcal_ba_info* out);
+
+void lifcal_ba_destroy(lifcal_ba_handle* h);
+const char* lifcal_ba_strerror(int code);
+const char* lifcal_ba_last_error(void);
+const char* lifcal_ba_version(void);
+
+/* Host-only planning (no device needed): the observation re-ordering create() performs.
+ * Exposed so the CPU test-suite can check the layout invariants without a GPU. */
+typedef struct lifcal_ba_plan_info {
+  uint32_t n_groups, n_tiles, n_lenses, n_promoted, n_reduced, max_group_obs, n_chunks, max_window_frames;
+} lifcal_ba_plan_info;
+int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size,
+                   lifcal_ba_plan_info* info,
+                   uint32_t* obs_order /* [n_obs] or NULL: sorted position -> input index, UINT32_MAX-padded */,
+                   uint32_t* point_owner /* [n_points] or NULL: rank owning each point */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIFCAL_BA_H */

@@ -1,0 +1,203 @@
+"""ctypes view of include/lifcal_ba.h (struct layouts + prototypes).  Plumbing only."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "liblifcal_ba.so")
+
+dptr = C.POINTER(C.c_double)
+uptr = C.POINTER(C.c_uint32)
+
+
+class Problem(C.Structure):
+    _fields_ = [
+        ("n_obs", C.c_uint32), ("n_frames", C.c_uint32), ("n_points", C.c_uint32), ("n_constraints", C.c_uint32),
+        ("u", dptr), ("v", dptr), ("mcx", dptr), ("mcy", dptr), ("pt", uptr), ("fr", uptr),
+        ("cam", dptr), ("views", dptr), ("pts", dptr),
+        ("spx", C.c_double), ("spy", C.c_double), ("scale", C.c_double),
+        ("config", C.c_uint32), ("fixed_mask", C.c_uint32),
+        ("lower", dptr), ("upper", dptr),
+        ("c_i", uptr), ("c_j", uptr), ("c_dist", dptr), ("c_sigma", dptr),
+        ("use_constraints", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class Options(C.Structure):
+    _fields_ = [
+        ("function_tolerance", C.c_double), ("parameter_tolerance", C.c_double), ("gradient_tolerance", C.c_double),
+        ("initial_radius", C.c_double), ("max_radius", C.c_double), ("min_radius", C.c_double),
+        ("min_relative_decrease", C.c_double), ("min_lm_diagonal", C.c_double), ("max_lm_diagonal", C.c_double),
+        ("loss_scale", C.c_double),
+        ("max_iterations", C.c_int32), ("jacobi_scaling", C.c_int32), ("precision", C.c_int32), ("device", C.c_int32),
+        ("rank", C.c_int32), ("world_size", C.c_int32), ("verbose", C.c_int32), ("deterministic", C.c_int32),
+    ]
+
+
+class Summary(C.Structure):
+    _fields_ = [
+        ("initial_cost", C.c_double), ("final_cost", C.c_double), ("final_radius", C.c_double),
+        ("final_gradient_max_norm", C.c_double),
+        ("iterations", C.c_int32), ("successful_steps", C.c_int32), ("unsuccessful_steps", C.c_int32),
+        ("termination", C.c_int32),
+        ("seconds_total", C.c_double), ("seconds_sweep", C.c_double), ("seconds_linear_solve", C.c_double),
+    ]
+
+
+class SweepOut(C.Structure):
+    _fields_ = [
+        ("cost", C.c_double), ("gradient_max_norm", C.c_double),
+        ("n_reduced", C.c_uint32), ("n_promoted", C.c_uint32),
+        ("S", dptr), ("rhs", dptr), ("gradient_reduced", dptr), ("point_gradient", dptr), ("point_hessian_inv", dptr),
+        ("seconds", C.c_double),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [("std_x", C.c_double), ("std_y", C.c_double), ("mae_x", C.c_double), ("mae_y", C.c_double),
+                ("num_points", C.c_uint32), ("num_inliers", C.c_uint32)]
+
+
+class Info(C.Structure):
+    _fields_ = [("n_obs_local", C.c_uint32), ("n_points_local", C.c_uint32), ("n_groups", C.c_uint32),
+                ("n_tiles", C.c_uint32), ("n_lenses", C.c_uint32), ("n_reduced", C.c_uint32), ("n_promoted", C.c_uint32),
+                ("n_chunks", C.c_uint32), ("max_window_frames", C.c_uint32),
+                ("device_bytes", C.c_uint64), ("stream", C.c_void_p)]
+
+
+class PlanInfo(C.Structure):
+    _fields_ = [("n_groups", C.c_uint32), ("n_tiles", C.c_uint32), ("n_lenses", C.c_uint32), ("n_promoted", C.c_uint32),
+                ("n_reduced", C.c_uint32), ("max_group_obs", C.c_uint32), ("n_chunks", C.c_uint32),
+                ("max_window_frames", C.c_uint32)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+# every symbol include/lifcal_ba.h declares: name -> (restype, argtypes)
+PROTOTYPES = {
+    "lifcal_ba_default_options": (None, [C.POINTER(Options)]),
+    "lifcal_ba_create": (C.c_int, [C.POINTER(Problem), C.POINTER(Options), C.POINTER(C.c_void_p)]),
+    "lifcal_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(Summary)]),
+    "lifcal_ba_sweep": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(SweepOut)]),
+    "lifcal_ba_reproj_stats": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(Stats)]),
+    "lifcal_ba_upload_parameters": (C.c_int, [C.c_void_p]),
+    "lifcal_ba_download_parameters": (C.c_int, [C.c_void_p]),
+    "lifcal_ba_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "lifcal_ba_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "lifcal_ba_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "lifcal_ba_get_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
+    "lifcal_ba_destroy": (None, [C.c_void_p]),
+    "lifcal_ba_strerror": (C.c_char_p, [C.c_int]),
+    "lifcal_ba_last_error": (C.c_char_p, []),
+    "lifcal_ba_version": (C.c_char_p, []),
+    "lifcal_ba_plan": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, C.POINTER(PlanInfo), uptr, uptr]),
+}
+
+_lib = None
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    """Load the HIP extension.  Fails loudly: there is no Python/CPU fallback for the hot path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"lifcal_amd: native library {path} is missing. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                "There is no CPU fallback for the bundle-adjustment path.")
+        lib = C.CDLL(path)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def as_dptr(a: np.ndarray):
+    return a.ctypes.data_as(dptr) if a is not None else None
+
+
+def as_uptr(a: np.ndarray):
+    return a.ctypes.data_as(uptr) if a is not None else None
+
+
+class ProblemArrays:
+    """Owns contiguous numpy buffers and the ctypes struct that points into them."""
+
+    def __init__(self, u, v, mcx, mcy, pt, fr, cam, views, pts, spx, scale, config, spy=None,
+                 fixed_mask=0, lower=None, upper=None, c_i=None, c_j=None, c_dist=None, c_sigma=None,
+                 use_constraints=1):
+        f8 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+        u4 = lambda a: np.ascontiguousarray(np.asarray(a, dtype=np.uint32).reshape(-1))
+        self.u, self.v, self.mcx, self.mcy = f8(u), f8(v), f8(mcx), f8(mcy)
+        self.pt, self.fr = u4(pt), u4(fr)
+        self.cam = f8(cam).copy()
+        self.views = f8(views).copy()
+        self.pts = f8(pts).copy()
+        assert self.cam.shape[0] == 17
+        self.lower = f8(lower) if lower is not None else None
+        self.upper = f8(upper) if upper is not None else None
+        m = 0 if c_i is None else len(np.asarray(c_i).reshape(-1))
+        self.c_i = u4(c_i) if m else None
+        self.c_j = u4(c_j) if m else None
+        self.c_dist = f8(c_dist) if m else None
+        self.c_sigma = f8(c_sigma) if m else None
+        p = Problem()
+        p.n_obs = self.u.shape[0]
+        p.n_frames = self.views.shape[0] // 6
+        p.n_points = self.pts.shape[0] // 3
+        p.n_constraints = m
+        p.u, p.v, p.mcx, p.mcy = as_dptr(self.u), as_dptr(self.v), as_dptr(self.mcx), as_dptr(self.mcy)
+        p.pt, p.fr = as_uptr(self.pt), as_uptr(self.fr)
+        p.cam, p.views, p.pts = as_dptr(self.cam), as_dptr(self.views), as_dptr(self.pts)
+        p.spx = float(spx)
+        p.spy = float(spx if spy is None else spy)
+        p.scale = float(scale)
+        p.config = int(config)
+        p.fixed_mask = int(fixed_mask)
+        p.lower = as_dptr(self.lower) if self.lower is not None else None
+        p.upper = as_dptr(self.upper) if self.upper is not None else None
+        p.c_i = as_uptr(self.c_i) if m else None
+        p.c_j = as_uptr(self.c_j) if m else None
+        p.c_dist = as_dptr(self.c_dist) if m else None
+        p.c_sigma = as_dptr(self.c_sigma) if m else None
+        p.use_constraints = int(use_constraints)
+        self.struct = p
+
+    @classmethod
+    def from_scene(cls, scene, initial=True):
+        return cls(scene.u, scene.v, scene.mcx, scene.mcy, scene.pt, scene.fr,
+                   scene.cam0 if initial else scene.cam_gt,
+                   scene.views0 if initial else scene.views_gt,
+                   scene.pts0 if initial else scene.pts_gt,
+                   scene.spx, scene.scale, scene.config, fixed_mask=scene.fixed_mask,
+                   lower=scene.lower, upper=scene.upper, c_i=scene.c_i, c_j=scene.c_j,
+                   c_dist=scene.c_dist, c_sigma=scene.c_sigma, use_constraints=scene.use_constraints)
+
+
+def default_options_py() -> Options:
+    """The same defaults lifcal_ba_default_options() writes (used when the .so is not needed)."""
+    o = Options()
+    o.function_tolerance = 1e-6
+    o.parameter_tolerance = 1e-8
+    o.gradient_tolerance = 1e-10
+    o.initial_radius = 1e4
+    o.max_radius = 1e16
+    o.min_radius = 1e-32
+    o.min_relative_decrease = 1e-3
+    o.min_lm_diagonal = 1e-6
+    o.max_lm_diagonal = 1e32
+    o.loss_scale = 0.5
+    o.max_iterations = 200
+    o.jacobi_scaling = 1
+    o.precision = 0
+    o.device = 0
+    o.rank = 0
+    o.world_size = 1
+    o.verbose = 0
+    o.deterministic = 0
+    return o
