@@ -1,0 +1,156 @@
+"""Host-side mirror of LiFCal's bundle-adjustment seam on top of the C ABI (include/lifcal_ba.h).
+
+Names follow the reference (src/CameraCalibration.{h,cpp}):
+    performBundleAdjustment()  <- CameraCalibration::performBundleAdjustment  (:774-992)
+    calcReprojectionError()    <- CameraCalibration::calcReprojectionError    (:1026-1103)
+    make_config()              <- the config bitmask assembly                  (:778-814)
+The arithmetic lives in the HIP library; this file only flattens arguments and forwards them.
+There is no Python/CPU fallback: if the library is missing, loading raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _capi as capi
+
+
+def make_config(nRadialDistParam=2, tangentialDistParam=True, refinePoses=True, useRobustCostFunction=True,
+                refine3Dpoints=True, mlCenterAdjustment=True) -> int:
+    """reference src/CameraCalibration.cpp:778-814 (nRadialDistParam is clamped to 2 at :786)."""
+    cfg = min(int(nRadialDistParam), 2) & 0x3
+    if tangentialDistParam:
+        cfg |= 0x004
+    if refinePoses:
+        cfg |= 0x100
+    if useRobustCostFunction:
+        cfg |= 0x200
+    if refine3Dpoints:
+        cfg |= 0x400
+    if mlCenterAdjustment:
+        cfg |= 0x800
+    return cfg
+
+
+class LifcalError(RuntimeError):
+    pass
+
+
+def _check(lib, rc, what):
+    if rc != 0:
+        raise LifcalError(f"{what}: {lib.lifcal_ba_strerror(rc).decode()} ({rc}) {lib.lifcal_ba_last_error().decode()}")
+
+
+class BundleAdjustment:
+    """One bundle-adjustment problem resident on one MI355X (one rank of a point-sharded job)."""
+
+    def __init__(self, problem: capi.ProblemArrays, options: Optional[capi.Options] = None):
+        self.lib = capi.load_library()
+        self.problem = problem
+        if options is None:
+            options = capi.Options()
+            self.lib.lifcal_ba_default_options(C.byref(options))
+        self.options = options
+        self._h = C.c_void_p()
+        self._hook = None
+        _check(self.lib, self.lib.lifcal_ba_create(C.byref(problem.struct), C.byref(options), C.byref(self._h)), "lifcal_ba_create")
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            self.lib.lifcal_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- the reference's two entry points ------------------------------------------------------
+    def performBundleAdjustment(self) -> capi.Summary:
+        """Runs LM to termination; cam/views/pts of `problem` are updated in place (reference :965-988)."""
+        s = capi.Summary()
+        _check(self.lib, self.lib.lifcal_ba_solve(self._h, C.byref(s)), "lifcal_ba_solve")
+        return s
+
+    def calcReprojectionError(self, inlierThreshold: float = 1.0) -> capi.Stats:
+        st = capi.Stats()
+        _check(self.lib, self.lib.lifcal_ba_reproj_stats(self._h, inlierThreshold, C.byref(st)), "lifcal_ba_reproj_stats")
+        return st
+
+    # -- the benchmarked unit ------------------------------------------------------------------
+    def sweep(self, radius: float = 1e4, want_matrices: bool = False):
+        """One Jacobian+Schur sweep; returns a namespace with cost, gradient_max_norm, seconds and,
+        if requested, S / rhs / gradient_reduced / point_gradient / point_hessian_inv (canonical order)."""
+        info = self.info()
+        out = capi.SweepOut()
+        res = type("Sweep", (), {})()
+        if want_matrices:
+            n = info.n_reduced
+            P = self.problem.struct.n_points
+            res.S = np.zeros((n, n)); res.rhs = np.zeros(n); res.gradient_reduced = np.zeros(n)
+            res.point_gradient = np.zeros(3 * P); res.point_hessian_inv = np.zeros(9 * P)
+            out.S, out.rhs, out.gradient_reduced = capi.as_dptr(res.S), capi.as_dptr(res.rhs), capi.as_dptr(res.gradient_reduced)
+            out.point_gradient, out.point_hessian_inv = capi.as_dptr(res.point_gradient), capi.as_dptr(res.point_hessian_inv)
+        _check(self.lib, self.lib.lifcal_ba_sweep(self._h, float(radius), C.byref(out)), "lifcal_ba_sweep")
+        res.cost = out.cost; res.gradient_max_norm = out.gradient_max_norm; res.seconds = out.seconds
+        res.n_reduced = out.n_reduced; res.n_promoted = out.n_promoted
+        return res
+
+    def sweep_raw(self, radius: float, out: capi.SweepOut) -> int:
+        """Thin call for timing loops (no Python allocation)."""
+        return self.lib.lifcal_ba_sweep(self._h, radius, C.byref(out))
+
+    # -- plumbing --------------------------------------------------------------------------------
+    def upload_parameters(self):
+        _check(self.lib, self.lib.lifcal_ba_upload_parameters(self._h), "lifcal_ba_upload_parameters")
+
+    def download_parameters(self):
+        _check(self.lib, self.lib.lifcal_ba_download_parameters(self._h), "lifcal_ba_download_parameters")
+
+    def info(self) -> capi.Info:
+        i = capi.Info()
+        _check(self.lib, self.lib.lifcal_ba_get_info(self._h, C.byref(i)), "lifcal_ba_get_info")
+        return i
+
+    def set_allreduce(self, fn):
+        """fn(device_ptr:int, count:int, stream:int) -> 0 on success; must sum-reduce in place."""
+        def tramp(ctx, buf, count, stream):
+            try:
+                return int(fn(int(buf or 0), int(count), int(stream or 0)))
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._hook = capi.ALLREDUCE_FN(tramp)
+        _check(self.lib, self.lib.lifcal_ba_set_allreduce(self._h, self._hook, None), "lifcal_ba_set_allreduce")
+
+    def comm_init_rccl(self, unique_id: bytes):
+        buf = C.create_string_buffer(unique_id, 128)
+        _check(self.lib, self.lib.lifcal_ba_comm_init_rccl(self._h, buf), "lifcal_ba_comm_init_rccl")
+
+
+def comm_unique_id() -> bytes:
+    lib = capi.load_library()
+    buf = C.create_string_buffer(128)
+    _check(lib, lib.lifcal_ba_comm_unique_id(buf), "lifcal_ba_comm_unique_id")
+    return buf.raw
+
+
+def plan(problem: capi.ProblemArrays, rank: int = 0, world_size: int = 1):
+    """Host-only layout planning (no GPU needed): returns (PlanInfo, obs_order, point_owner)."""
+    lib = capi.load_library()
+    info = capi.PlanInfo()
+    order = np.zeros(max(problem.struct.n_obs, 1), np.uint32)
+    owner = np.zeros(max(problem.struct.n_points, 1), np.uint32)
+    _check(lib, lib.lifcal_ba_plan(C.byref(problem.struct), rank, world_size, C.byref(info), capi.as_uptr(order), capi.as_uptr(owner)), "lifcal_ba_plan")
+    return info, order[: problem.struct.n_obs], owner[: problem.struct.n_points].astype(np.int32)

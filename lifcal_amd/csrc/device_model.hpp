@@ -1,0 +1,252 @@
+// device_model.hpp — plenoptic camera model with a hand-derived analytic Jacobian (gfx950 device code).
+//
+// What it computes (same mathematics as the reference, different algorithm):
+//   reference src/CameraModel.h:86-199   CameraModel::projectPoint<T>          -> lens_eval + obs_eval / obs_value
+//   reference src/CameraModel.h:205-241  radialDistortion / tangentialDistortion -> distortion()
+//   reference src/CameraModel.h:246-264  RigidBody::getTransformationMatrix<T>  -> frame_eval
+//   reference src/BundleAdjustment/BundleAdjustment.h:120-195 operator_function -> cam_prepare (sign folding) + obs_eval
+// The reference differentiates this with ceres::Jet<double,26> per observation (≈38 kflop); here
+//   * everything that depends on the camera only is computed once (CamConsts),
+//   * the 10-sweep undistortion of the micro-lens centre and its tangents w.r.t. (c_raw, k, p) is
+//     tabulated per UNIQUE lens (lens_eval) — the tangent recurrence unrolls the same fixed-point
+//     sweeps autodiff would, so the derivative is that of the truncated iteration, not the implicit one,
+//   * the rotation and translation are tabulated per frame (frame_eval),
+//   * per observation only the closed-form chain remains (obs_eval): residual r[2],
+//     Jq = dr/d(camera-frame point) [2x3] and Jc = dr/d(camera slots) [2xNC].
+// Pose and point Jacobians follow from Jq per (point, frame) group: J_t = Jq, J_a = Jq [ax_k x (R P)],
+// J_P = Jq R (see group_transform in kernels.hpp).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace lifcal {
+
+#define LIFCAL_DEV __device__ __forceinline__
+
+constexpr int NCMAX = 9;       // 5 + 2 radial + 2 tangential live camera slots
+constexpr int LENS_STRIDE = 16;  // doubles per lens-table entry
+constexpr int FRAME_STRIDE = 16; // doubles per frame-table entry
+
+// Camera-only quantities.  Model parameters theta = (fL, bL0, B, c_raw.x, c_raw.y, k1, k2, p1, p2);
+// chm[j] = d theta_j / d camera[j] (sign folding / +-scale) times the free-column mask.
+struct CamConsts {
+  double fL, bL0, B, ifL;
+  double craw[2];
+  double sp[2], isp[2];
+  double D, iD, e, zC0, gamma, beta;
+  double de[3], dzC0[3], dgamma[3], dbeta[3];
+  double a, da[3];
+  double k[2], p[2];
+  double chm[NCMAX];
+  double loss_b, loss_c;
+};
+
+// reference BundleAdjustment.h:123-146 (fold = true) or CameraCalibration.cpp:1028-1039 (fold = false,
+// scale cast through float as calcReprojectionError does)
+LIFCAL_DEV void cam_prepare(const double* cam, double spx, double spy, double scale, int n_radial, bool tangential,
+                            unsigned fixed_mask, double loss_scale, bool fold, CamConsts& c) {
+  double sg[3] = {1.0, 1.0, 1.0};
+  double th[3];
+  for (int i = 0; i < 3; ++i) { th[i] = cam[i]; if (fold && th[i] < 0.0) { th[i] = -th[i]; sg[i] = -1.0; } }
+  c.fL = th[0]; c.bL0 = th[1]; c.B = th[2]; c.ifL = 1.0 / c.fL;
+  double dcr[2];
+  for (int i = 0; i < 2; ++i) {
+    double v = (cam[3 + i] + 0.5) * scale - 0.5; dcr[i] = scale;
+    if (fold && v < 0.0) { v = -v; dcr[i] = -scale; }
+    c.craw[i] = v;
+  }
+  c.sp[0] = spx / scale; c.sp[1] = spy / scale; c.isp[0] = 1.0 / c.sp[0]; c.isp[1] = 1.0 / c.sp[1];
+  const double D = c.fL - c.bL0, iD = 1.0 / D, iD2 = iD * iD;
+  c.D = D; c.iD = iD;
+  c.e = c.fL * iD; c.zC0 = c.fL * c.bL0 * iD; c.gamma = c.fL * c.B * iD; c.beta = c.B * iD;
+  c.de[0] = -c.bL0 * iD2;          c.de[1] = c.fL * iD2;           c.de[2] = 0.0;
+  c.dzC0[0] = -c.bL0 * c.bL0 * iD2; c.dzC0[1] = c.fL * c.fL * iD2;   c.dzC0[2] = 0.0;
+  c.dgamma[0] = -c.B * c.bL0 * iD2; c.dgamma[1] = c.fL * c.B * iD2;  c.dgamma[2] = c.fL * iD;
+  c.dbeta[0] = -c.B * iD2;          c.dbeta[1] = c.B * iD2;          c.dbeta[2] = iD;
+  const double s = c.bL0 + c.B, is = 1.0 / s;
+  c.a = c.bL0 * is; c.da[0] = 0.0; c.da[1] = c.B * is * is; c.da[2] = -c.bL0 * is * is;
+  c.k[0] = n_radial > 0 ? cam[5] : 0.0; c.k[1] = n_radial > 1 ? cam[6] : 0.0;
+  c.p[0] = tangential ? cam[5 + n_radial] : 0.0; c.p[1] = tangential ? cam[6 + n_radial] : 0.0;
+  const int nc = 5 + n_radial + (tangential ? 2 : 0);
+  for (int j = 0; j < NCMAX; ++j) {
+    double ch = 1.0;
+    if (j < 3) ch = sg[j]; else if (j < 5) ch = dcr[j - 3];
+    const bool live = (j < nc) && !((fixed_mask >> j) & 1u);
+    c.chm[j] = live ? ch : 0.0;
+  }
+  c.loss_b = loss_scale * loss_scale; c.loss_c = 1.0 / c.loss_b;
+}
+
+// Distortion value Delta(x,y) (reference CameraModel.h:205-241), its 2x2 Jacobian A and the explicit
+// partials w.r.t. k_i, p_i.  NR / TAN are compile-time so unused terms vanish.
+template <int NR, bool TAN>
+struct Distortion {
+  double dx, dy, A00, A01, A10, A11, r2, r4;
+  LIFCAL_DEV void eval(double x, double y, const CamConsts& c, bool want_jac) {
+    r2 = x * x + y * y; r4 = r2 * r2;
+    double g = 0.0, gp = 0.0;
+    if (NR >= 1) { g = c.k[0] * r2; gp = c.k[0]; }
+    if (NR >= 2) { g += c.k[1] * r4; gp += 2.0 * c.k[1] * r2; }
+    dx = x * g; dy = y * g;
+    if (want_jac) { const double xy2 = 2.0 * x * y * gp; A00 = g + 2.0 * x * x * gp; A01 = xy2; A10 = xy2; A11 = g + 2.0 * y * y * gp; }
+    if (TAN) {
+      dx += c.p[0] * (r2 + 2.0 * x * x) + 2.0 * c.p[1] * x * y;
+      dy += c.p[1] * (r2 + 2.0 * y * y) + 2.0 * c.p[0] * x * y;
+      if (want_jac) {
+        A00 += 6.0 * c.p[0] * x + 2.0 * c.p[1] * y; A01 += 2.0 * c.p[0] * y + 2.0 * c.p[1] * x;
+        A10 += 2.0 * c.p[1] * x + 2.0 * c.p[0] * y; A11 += 6.0 * c.p[1] * y + 2.0 * c.p[0] * x;
+      }
+    }
+  }
+  // explicit partial of Delta w.r.t. lens-parameter a (0: c_raw.x, 1: c_raw.y, 2..: k, then p)
+  LIFCAL_DEV void explicit_partial(int a, double x, double y, double& ex, double& ey) const {
+    ex = 0.0; ey = 0.0;
+    if (NR >= 1 && a == 2) { ex = x * r2; ey = y * r2; }
+    if (NR >= 2 && a == 3) { ex = x * r4; ey = y * r4; }
+    if (TAN && a == 2 + NR) { ex = r2 + 2.0 * x * x; ey = 2.0 * x * y; }
+    if (TAN && a == 3 + NR) { ex = 2.0 * x * y; ey = r2 + 2.0 * y * y; }
+  }
+};
+
+// Lens-table entry: [0,1] lens centre, [2,3] undistorted centre c_u (mm, before the mlCenterAdj factor),
+// [4+2a, 5+2a] d c_u / d lens-parameter a, a < NA = 2 + NR + 2*TAN.
+template <int NR, bool TAN>
+LIFCAL_DEV void lens_eval(const CamConsts& c, double mx, double my, bool want_tangents, double* out) {
+  constexpr int NA = 2 + NR + (TAN ? 2 : 0);
+  const double cdx = (mx - c.craw[0]) * c.sp[0], cdy = (my - c.craw[1]) * c.sp[1];
+  double x = cdx, y = cdy;
+  double tx[NA], ty[NA], d0x[NA], d0y[NA];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) { d0x[a] = (a == 0) ? -c.sp[0] : 0.0; d0y[a] = (a == 1) ? -c.sp[1] : 0.0; tx[a] = d0x[a]; ty[a] = d0y[a]; }
+  if (NR > 0 || TAN) {
+    Distortion<NR, TAN> d;
+    for (int it = 0; it < 10; ++it) {  // reference CameraModel.h:109-124
+      d.eval(x, y, c, want_tangents);
+      if (want_tangents) {
+#pragma unroll
+        for (int a = 0; a < NA; ++a) {
+          double ex, ey; d.explicit_partial(a, x, y, ex, ey);
+          const double nx = d0x[a] - (d.A00 * tx[a] + d.A01 * ty[a]) - ex;
+          const double ny = d0y[a] - (d.A10 * tx[a] + d.A11 * ty[a]) - ey;
+          tx[a] = nx; ty[a] = ny;
+        }
+      }
+      x = cdx - d.dx; y = cdy - d.dy;
+    }
+  }
+  out[0] = mx; out[1] = my; out[2] = x; out[3] = y;
+  if (want_tangents) {
+#pragma unroll
+    for (int a = 0; a < NA; ++a) { out[4 + 2 * a] = tx[a]; out[5 + 2 * a] = ty[a]; }
+  }
+}
+
+// Frame-table entry: [0..8] R row-major (R = Rx Ry Rz), [9..11] t, [12] cos a0, [13] sin a0.
+// d(R P)/d a0 = e_x x (R P), d/d a1 = (0, cos a0, sin a0) x (R P), d/d a2 = R[:,2] x (R P).
+LIFCAL_DEV void frame_eval(const double* view, double* out) {
+  double s0, c0, s1, c1, s2, c2;
+  sincos(view[0], &s0, &c0); sincos(view[1], &s1, &c1); sincos(view[2], &s2, &c2);
+  out[0] = c1 * c2;                 out[1] = -c1 * s2;                out[2] = s1;
+  out[3] = c0 * s2 + s0 * s1 * c2;  out[4] = c0 * c2 - s0 * s1 * s2;  out[5] = -s0 * c1;
+  out[6] = s0 * s2 - c0 * s1 * c2;  out[7] = s0 * c2 + c0 * s1 * s2;  out[8] = c0 * c1;
+  out[9] = view[3]; out[10] = view[4]; out[11] = view[5];
+  out[12] = c0; out[13] = s0; out[14] = 0.0; out[15] = 0.0;
+}
+
+// quantities shared by all observations of one (point, frame) group
+struct GroupConsts {
+  double X, Y, iZq;     // camera-frame point, 1/(Z + zC0)
+  double kq[3], kw[3];  // d pMl / d(fL,bL0,B) = q * kq + w * kw + mu * dw
+  double mu, gz;        // gamma e iZq - beta ; gamma iZq
+};
+
+LIFCAL_DEV void group_prepare(const CamConsts& c, double X, double Y, double Z, GroupConsts& g) {
+  g.X = X; g.Y = Y; g.iZq = 1.0 / (Z + c.zC0);
+  g.gz = c.gamma * g.iZq;
+  g.mu = g.gz * c.e - c.beta;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { g.kq[i] = c.dgamma[i] - g.gz * c.dzC0[i]; g.kw[i] = g.gz * c.de[i] - c.dbeta[i]; }
+}
+
+// value-only projection residual (cost evaluation, reprojection statistics)
+template <int NR, bool TAN, bool ADJ>
+LIFCAL_DEV void obs_value(const CamConsts& c, const GroupConsts& g, double mx, double my, double cux, double cuy,
+                          double u, double v, double& rx, double& ry) {
+  const double wx = ADJ ? cux * c.a : cux, wy = ADJ ? cuy * c.a : cuy;
+  const double qx = (g.X + wx * c.e) * g.iZq, qy = (g.Y + wy * c.e) * g.iZq;
+  const double mlx = c.gamma * qx - c.beta * wx, mly = c.gamma * qy - c.beta * wy;
+  double px, py;
+  if (ADJ) {
+    px = mlx + wx; py = mly + wy;
+    if (NR > 0 || TAN) { Distortion<NR, TAN> d; d.eval(px, py, c, false); px += d.dx; py += d.dy; }
+  } else {
+    px = mlx + (mx - c.craw[0]) * c.sp[0]; py = mly + (my - c.craw[1]) * c.sp[1];
+  }
+  rx = px * c.isp[0] + c.craw[0] - u;
+  ry = py * c.isp[1] + c.craw[1] - v;
+}
+
+// residual + analytic Jacobian of one observation.  L = lens-table entry (with tangents).
+// Jc[row][j]: j indexes the live camera slots in camera[] order (fL,bL0,B,cx,cy,k..,p..).
+template <int NR, bool TAN, bool ADJ>
+LIFCAL_DEV void obs_eval(const CamConsts& c, const GroupConsts& g, const double* __restrict__ L, double u, double v,
+                         double r[2], double Jq[2][3], double Jc[2][5 + NR + (TAN ? 2 : 0)]) {
+  constexpr int NA = 2 + NR + (TAN ? 2 : 0);
+  constexpr int NC = 3 + NA;
+  const double mx = L[0], my = L[1], cux = L[2], cuy = L[3];
+  const double wx = ADJ ? cux * c.a : cux, wy = ADJ ? cuy * c.a : cuy;
+  const double qx = (g.X + wx * c.e) * g.iZq, qy = (g.Y + wy * c.e) * g.iZq;
+  const double mlx = c.gamma * qx - c.beta * wx, mly = c.gamma * qy - c.beta * wy;
+  // d(pMl)/d theta: columns 0..2 = (fL,bL0,B), 3.. = lens parameters
+  double dx[NC], dy[NC];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    dx[i] = qx * g.kq[i] + wx * g.kw[i];
+    dy[i] = qy * g.kq[i] + wy * g.kw[i];
+    if (ADJ) { dx[i] += g.mu * cux * c.da[i]; dy[i] += g.mu * cuy * c.da[i]; }
+  }
+  const double wscale = ADJ ? c.a : 1.0;
+#pragma unroll
+  for (int a = 0; a < NA; ++a) { dx[3 + a] = g.mu * wscale * L[4 + 2 * a]; dy[3 + a] = g.mu * wscale * L[5 + 2 * a]; }
+  // d(pMl)/d p_c
+  double qxX = g.gz, qxZ = -g.gz * qx, qyY = g.gz, qyZ = -g.gz * qy;
+  double px, py;
+  double j00, j01, j02, j10, j11, j12;  // d proj / d (X,Y,Z)
+  if (ADJ) {
+    // proj0 = pMl + w ; proj = proj0 + Delta(proj0)   (reference CameraModel.h:152-176)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { dx[i] += cux * c.da[i]; dy[i] += cuy * c.da[i]; }
+#pragma unroll
+    for (int a = 0; a < NA; ++a) { dx[3 + a] += wscale * L[4 + 2 * a]; dy[3 + a] += wscale * L[5 + 2 * a]; }
+    px = mlx + wx; py = mly + wy;
+    if (NR > 0 || TAN) {
+      Distortion<NR, TAN> d; d.eval(px, py, c, true);
+      const double b00 = 1.0 + d.A00, b01 = d.A01, b10 = d.A10, b11 = 1.0 + d.A11;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        double ex = 0.0, ey = 0.0;
+        if (i >= 3) d.explicit_partial(i - 3, px, py, ex, ey);
+        const double nx = b00 * dx[i] + b01 * dy[i] + ex, ny = b10 * dx[i] + b11 * dy[i] + ey;
+        dx[i] = nx; dy[i] = ny;
+      }
+      j00 = b00 * qxX; j01 = b01 * qyY; j02 = b00 * qxZ + b01 * qyZ;
+      j10 = b10 * qxX; j11 = b11 * qyY; j12 = b10 * qxZ + b11 * qyZ;
+      px += d.dx; py += d.dy;
+    } else {
+      j00 = qxX; j01 = 0.0; j02 = qxZ; j10 = 0.0; j11 = qyY; j12 = qyZ;
+    }
+    // out = proj / sp + c_raw : the c_raw term adds 1 to d/d c_raw
+    dx[3] += c.sp[0]; dy[4] += c.sp[1];
+  } else {
+    // proj = pMl + c_d (reference :187-190); d c_d/d c_raw = -sp cancels the +1 of "+ c_raw" exactly
+    px = mlx + (mx - c.craw[0]) * c.sp[0]; py = mly + (my - c.craw[1]) * c.sp[1];
+    j00 = qxX; j01 = 0.0; j02 = qxZ; j10 = 0.0; j11 = qyY; j12 = qyZ;
+  }
+  r[0] = px * c.isp[0] + c.craw[0] - u;
+  r[1] = py * c.isp[1] + c.craw[1] - v;
+  Jq[0][0] = j00 * c.isp[0]; Jq[0][1] = j01 * c.isp[0]; Jq[0][2] = j02 * c.isp[0];
+  Jq[1][0] = j10 * c.isp[1]; Jq[1][1] = j11 * c.isp[1]; Jq[1][2] = j12 * c.isp[1];
+#pragma unroll
+  for (int j = 0; j < NC; ++j) { Jc[0][j] = dx[j] * c.isp[0] * c.chm[j]; Jc[1][j] = dy[j] * c.isp[1] * c.chm[j]; }
+}
+
+}  // namespace lifcal

@@ -1,0 +1,821 @@
+// kernels.hpp — gfx950 kernels of the bundle-adjustment hot path (wave64, fp64).
+//
+// Sweep = what ceres does per LM iteration for the reference:
+//   k_tables      camera constants, frame table, lens table          (hoisted out of the per-obs functor)
+//   k_sweep       residual + analytic Jacobian per observation, robust weights (CauchyLoss(0.5),
+//                 reference src/CameraCalibration.cpp:892), and the block accumulation
+//                 U_p, g_p, W_p (point blocks) and B, g_B (camera+pose blocks)
+//   k_constraints distance constraints (reference BundleAdjustment.h:255-279)
+//   k_schur       U_p + D_p -> inverse; S -= W^T U^-1 W ; rhs += W^T U^-1 g   (ceres SchurEliminator)
+//   k_finalize    LM diagonal on the reduced system, rhs, identity on fixed columns
+//   k_band_chol / k_band_backsolve   block-banded + arrow Cholesky of S (ceres DenseSchurComplementSolver)
+//   k_update_reduced / k_backsub     step for camera+poses, back-substitution for points, candidate point
+//   k_cost        candidate cost ; k_stats reprojection statistics (reference :1026-1103)
+//
+// Layout: one LANE owns one (point, frame) group and walks its ~6 observations; a wave is a tile of
+// 64 groups whose observation payload is stored [k][lane] so step k is one coalesced 512-B load per
+// array.  Everything shared by the group (camera-frame point, 1/(Z+zC0), pose) is computed once; the
+// per-observation outer products are accumulated in camera-frame space (A = sum Jq^T Jq, b = sum Jq^T r,
+// C = sum Jq^T Jc) and rotated into pose/point blocks once per group.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lifcal_ba.h"
+#include "device_model.hpp"
+
+namespace lifcal {
+
+constexpr int SCAL_COST = 0, SCAL_BAD_U = 1, SCAL_GMAX0 = 2, SCAL_N = 2 + 64;
+// host-visible scalars of one LM step
+constexpr int ST_GTD = 0, ST_DDD = 1, ST_STEP2 = 2, ST_X2 = 3, ST_CAND_COST = 4, ST_CHOL_FAIL = 5, ST_GMAX_RED = 6, ST_DIR = 7, ST_N = 8;
+
+struct Dev {
+  // sizes
+  uint32_t F, P, Q, NA, bw, nc, n_tiles, n_slots, n_lenses, n_red, ld, M_local, n_owned;
+  uint32_t n_radial, tangential, adj, robust, use_poses, use_points, rank, world;
+  uint32_t fixed_mask;
+  double spx, spy, scale, loss_scale;
+  double lm_min, lm_max;
+  // parameters (current / candidate)
+  double *cam, *views, *pts, *cam_c, *views_c, *pts_c;
+  const double *lower, *upper;  // 17 each or null
+  // tables
+  CamConsts *camc, *camc_c;
+  double *ft, *ft_c, *lt, *lt_c;
+  // observations
+  const uint32_t *tile_row0, *slot_pt, *slot_fr, *slot_cnt, *ell_lens;
+  const double *ell_u, *ell_v;
+  // points
+  const int32_t* promoted;       // P
+  const uint32_t* promoted_ids;  // Q
+  double* panel_g;               // global panel scratch for k_band_chol when it does not fit LDS (else null)
+  const uint32_t *pt_slot0, *pt_nslots, *owned;  // P, P, n_owned
+  const uint8_t* frame_live;     // F
+  double *ptacc;                 // P*36: U(6) g(3) Wc(27)
+  double *Uinv, *lamP, *sigP;    // 9P, 3P, 3P
+  double *Wv;                    // 18 per slot
+  // constraints
+  const uint32_t *c_i, *c_j, *my_cons, *pt_cons0, *pt_cons_list; const double *c_dist, *c_sigma;
+  double* Wpart;                 // 9 per constraint
+  // reduced system (one contiguous all-reduced block): Sband | Sarrow | rhsacc | gB | hdiag | scal
+  double *Sband, *Sarrow, *rhsacc, *gB, *hdiag, *scal;
+  double *sig_red, *lam_red, *delta_red, *Linv;  // n_red, n_red, n_red, 36F
+  double* step;                  // ST_N scalars
+};
+
+LIFCAL_DEV double* s_addr(const Dev& d, uint32_t row, uint32_t col) {  // row >= col, internal ordering
+  if (row < 6 * d.F) {
+    const uint32_t f = row / 6, i = row % 6, fc = col / 6, j = col % 6;
+    return d.Sband + ((size_t)f * (d.bw + 1) + (f - fc)) * 36 + i * 6 + j;
+  }
+  return d.Sarrow + (size_t)(row - 6 * d.F) * d.ld + col;
+}
+LIFCAL_DEV void s_add(const Dev& d, uint32_t row, uint32_t col, double v) {
+  if (row >= col) atomicAdd(s_addr(d, row, col), v); else atomicAdd(s_addr(d, col, row), v);
+}
+
+LIFCAL_DEV double wave_sum(double v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// tables
+// ---------------------------------------------------------------------------------------------
+__global__ void k_camc(const double* cam, CamConsts* out, double spx, double spy, double scale, int n_radial,
+                       int tangential, unsigned fixed_mask, double loss_scale, int fold) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    CamConsts c;
+    cam_prepare(cam, spx, spy, fold ? scale : (double)(float)scale, n_radial, tangential != 0, fixed_mask, loss_scale, fold != 0, c);
+    *out = c;
+  }
+}
+
+__global__ void k_frames(const double* views, double* ft, uint32_t F) {
+  const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < F) { double o[FRAME_STRIDE]; frame_eval(views + 6 * (size_t)f, o);
+#pragma unroll
+    for (int k = 0; k < FRAME_STRIDE; ++k) ft[(size_t)f * FRAME_STRIDE + k] = o[k]; }
+}
+
+template <int NR, bool TAN>
+__global__ void k_lenses(const CamConsts* camc, const double* lens_xy, double* lt, uint32_t n, int want_tangents) {
+  const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+  if (l >= n) return;
+  const CamConsts c = *camc;
+  double o[LENS_STRIDE];
+#pragma unroll
+  for (int k = 0; k < LENS_STRIDE; ++k) o[k] = 0.0;
+  lens_eval<NR, TAN>(c, lens_xy[2 * (size_t)l], lens_xy[2 * (size_t)l + 1], want_tangents != 0, o);
+#pragma unroll
+  for (int k = 0; k < LENS_STRIDE; ++k) lt[(size_t)l * LENS_STRIDE + k] = o[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// sweep: one lane per (point, frame) group
+// ---------------------------------------------------------------------------------------------
+template <int NR, bool TAN, bool ADJ>
+__global__ __launch_bounds__(256) void k_sweep(Dev d) {
+  constexpr int NC = 5 + NR + (TAN ? 2 : 0);
+  constexpr int NCC = NC * (NC + 1) / 2;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+  const CamConsts c = *d.camc;
+  double cc[NCC], gc[NC], cost = 0.0;
+#pragma unroll
+  for (int i = 0; i < NCC; ++i) cc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) gc[i] = 0.0;
+
+  for (uint32_t tile = wave; tile < d.n_tiles; tile += n_waves) {
+    const uint32_t slot = tile * 64 + lane;
+    const uint32_t cnt = d.slot_cnt[slot];
+    const uint32_t row0 = d.tile_row0[tile], kmax = d.tile_row0[tile + 1] - row0;
+    const uint32_t pt = d.slot_pt[slot], fr = d.slot_fr[slot];
+    double R[9], Y[3], c0 = 1.0, s0 = 0.0;
+    GroupConsts g;
+    {
+      const double* ft = d.ft + (size_t)fr * FRAME_STRIDE;
+      const double* P = d.pts + 3 * (size_t)pt;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R[k] = ft[k];
+      const double P0 = P[0], P1 = P[1], P2 = P[2];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) Y[k] = R[3 * k] * P0 + R[3 * k + 1] * P1 + R[3 * k + 2] * P2;
+      c0 = ft[12]; s0 = ft[13];
+      group_prepare(c, Y[0] + ft[9], Y[1] + ft[10], Y[2] + ft[11], g);
+    }
+    double A[6] = {0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0}, C[3][NC];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < NC; ++j) C[i][j] = 0.0;
+
+    for (uint32_t k = 0; k < kmax; ++k) {
+      if (k < cnt) {
+        const size_t at = ((size_t)row0 + k) * 64 + lane;
+        const double u = d.ell_u[at], v = d.ell_v[at];
+        const double* L = d.lt + (size_t)d.ell_lens[at] * LENS_STRIDE;
+        double r[2], Jq[2][3], Jc[2][NC];
+        obs_eval<NR, TAN, ADJ>(c, g, L, u, v, r, Jq, Jc);
+        const double sq = r[0] * r[0] + r[1] * r[1];
+        if (d.robust) {  // ceres::CauchyLoss + Corrector with rho'' < 0: scale r and J by sqrt(rho')
+          const double sum = 1.0 + sq * c.loss_c;
+          const double inv = 1.0 / sum;
+          cost += 0.5 * c.loss_b * log(sum);
+          const double sc = sqrt(fmax(inv, 2.2250738585072014e-308));
+          r[0] *= sc; r[1] *= sc;
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Jq[a][j] *= sc;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) Jc[a][j] *= sc;
+          }
+        } else {
+          cost += 0.5 * sq;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+          A[0] += Jq[a][0] * Jq[a][0]; A[1] += Jq[a][0] * Jq[a][1]; A[2] += Jq[a][0] * Jq[a][2];
+          A[3] += Jq[a][1] * Jq[a][1]; A[4] += Jq[a][1] * Jq[a][2]; A[5] += Jq[a][2] * Jq[a][2];
+#pragma unroll
+          for (int i = 0; i < 3; ++i) b[i] += Jq[a][i] * r[a];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < NC; ++j) C[i][j] += Jq[a][i] * Jc[a][j];
+          int t = 0;
+#pragma unroll
+          for (int i = 0; i < NC; ++i) {
+            gc[i] += Jc[a][i] * r[a];
+#pragma unroll
+            for (int j = 0; j <= i; ++j) cc[t++] += Jc[a][i] * Jc[a][j];
+          }
+        }
+      }
+    }
+
+    if (cnt > 0 && d.use_poses) {
+      const uint32_t F6 = 6 * d.F;
+      const double Am[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
+      // Gr = [e_x x Y, (0,c0,s0) x Y, R[:,2] x Y]
+      const double n0 = R[2], n1 = R[5], n2 = R[8];
+      const double Gr[3][3] = {{0.0, c0 * Y[2] - s0 * Y[1], n1 * Y[2] - n2 * Y[1]},
+                               {-Y[2], s0 * Y[0], n2 * Y[0] - n0 * Y[2]},
+                               {Y[1], -c0 * Y[0], n0 * Y[1] - n1 * Y[0]}};
+      double AG[3][3], GAG[3][3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) AG[i][j] = Am[i][0] * Gr[0][j] + Am[i][1] * Gr[1][j] + Am[i][2] * Gr[2][j];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) GAG[i][j] = Gr[0][i] * AG[0][j] + Gr[1][i] * AG[1][j] + Gr[2][i] * AG[2][j];
+      // pose-pose block (lower), pose gradient, pose diagonal
+      const uint32_t pr = 6 * fr;
+      double* Sd = d.Sband + (size_t)fr * (d.bw + 1) * 36;
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int bb = 0; bb <= a; ++bb) {
+          double v;
+          if (a < 3) v = GAG[a][bb]; else if (bb < 3) v = AG[a - 3][bb]; else v = Am[a - 3][bb - 3];
+          atomicAdd(Sd + a * 6 + bb, v);
+          if (a == bb) atomicAdd(d.hdiag + pr + a, v);
+        }
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        atomicAdd(d.gB + pr + a, Gr[0][a] * b[0] + Gr[1][a] * b[1] + Gr[2][a] * b[2]);
+        atomicAdd(d.gB + pr + 3 + a, b[a]);
+      }
+      // camera x pose block: cp[j][c] = C^T [Gr | I]
+      const uint32_t camrow = 3 * d.Q;
+#pragma unroll
+      for (int j = 0; j < NC; ++j) {
+        double* row = d.Sarrow + (size_t)(camrow + j) * d.ld + pr;
+#pragma unroll
+        for (int cidx = 0; cidx < 3; ++cidx) atomicAdd(row + cidx, C[0][j] * Gr[0][cidx] + C[1][j] * Gr[1][cidx] + C[2][j] * Gr[2][cidx]);
+#pragma unroll
+        for (int cidx = 0; cidx < 3; ++cidx) atomicAdd(row + 3 + cidx, C[cidx][j]);
+      }
+      if (d.use_points) {
+        double AR[3][3], U[3][3], gP[3], Wc[3][NC], Wv[3][6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) AR[i][j] = Am[i][0] * R[j] + Am[i][1] * R[3 + j] + Am[i][2] * R[6 + j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) U[i][j] = R[i] * AR[0][j] + R[3 + i] * AR[1][j] + R[6 + i] * AR[2][j];
+          gP[i] = R[i] * b[0] + R[3 + i] * b[1] + R[6 + i] * b[2];
+#pragma unroll
+          for (int j = 0; j < NC; ++j) Wc[i][j] = R[i] * C[0][j] + R[3 + i] * C[1][j] + R[6 + i] * C[2][j];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Wv[i][j] = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) Wv[i][3 + j] = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j];
+        }
+        // every point accumulates into its own slab; promoted points are scattered into the reduced
+        // system by k_schur (keeps this kernel free of divergent control flow)
+        double* acc = d.ptacc + (size_t)pt * 36;
+        atomicAdd(acc + 0, U[0][0]); atomicAdd(acc + 1, U[1][0]); atomicAdd(acc + 2, U[2][0]);
+        atomicAdd(acc + 3, U[1][1]); atomicAdd(acc + 4, U[2][1]); atomicAdd(acc + 5, U[2][2]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) atomicAdd(acc + 6 + i, gP[i]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < NC; ++j) atomicAdd(acc + 9 + i * NCMAX + j, Wc[i][j]);
+        double* wv = d.Wv + (size_t)slot * 18;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 6; ++j) wv[i * 6 + j] = Wv[i][j];
+      }
+    }
+  }
+  // camera x camera block, camera gradient, cost: reduce across the wave, one lane per value
+  const uint32_t camrow = 3 * d.Q, camcol = 6 * d.F + 3 * d.Q;
+  {
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const double s = wave_sum(cc[t]);
+        if (lane == (uint32_t)(t & 63)) { atomicAdd(d.Sarrow + (size_t)(camrow + i) * d.ld + camcol + j, s); if (i == j) atomicAdd(d.hdiag + camcol + i, s); }
+        ++t;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { const double s = wave_sum(gc[i]); if (lane == (uint32_t)i) atomicAdd(d.gB + camcol + i, s); }
+    const double s = wave_sum(cost);
+    if (lane == 63) atomicAdd(d.scal + SCAL_COST, s);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// distance constraints: r = (|Pi - Pj| - dist) / (sigma + 1e-6), squared loss; c_j is always promoted
+// ---------------------------------------------------------------------------------------------
+__global__ void k_constraints(Dev d, int cost_only, const double* pts, double* cost_out) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.M_local) return;
+  const uint32_t c = d.my_cons[t];
+  const uint32_t pi = d.c_i[c], pj = d.c_j[c];
+  const double* Pi = pts + 3 * (size_t)pi; const double* Pj = pts + 3 * (size_t)pj;
+  const double dx = Pi[0] - Pj[0], dy = Pi[1] - Pj[1], dz = Pi[2] - Pj[2];
+  const double n = sqrt(dx * dx + dy * dy + dz * dz);
+  const double is = 1.0 / (d.c_sigma[c] + 0.000001);
+  const double r = (n - d.c_dist[c]) * is;
+  atomicAdd(cost_out, 0.5 * r * r);
+  if (cost_only) return;
+  const double in = is / n;
+  const double Ji[3] = {dx * in, dy * in, dz * in};  // J_j = -J_i
+  const uint32_t F6 = 6 * d.F;
+  const int32_t qi = d.promoted[pi], qj = d.promoted[pj];
+  const uint32_t cj = F6 + 3 * (uint32_t)qj;
+  // endpoint j (promoted): block, gradient, diagonal
+  for (int a = 0; a < 3; ++a) {
+    for (int b = 0; b <= a; ++b) s_add(d, cj + a, cj + b, Ji[a] * Ji[b]);
+    atomicAdd(d.hdiag + cj + a, Ji[a] * Ji[a]);
+    atomicAdd(d.gB + cj + a, -Ji[a] * r);
+  }
+  if (qi < 0) {
+    double* acc = d.ptacc + (size_t)pi * 36;
+    atomicAdd(acc + 0, Ji[0] * Ji[0]); atomicAdd(acc + 1, Ji[1] * Ji[0]); atomicAdd(acc + 2, Ji[2] * Ji[0]);
+    atomicAdd(acc + 3, Ji[1] * Ji[1]); atomicAdd(acc + 4, Ji[2] * Ji[1]); atomicAdd(acc + 5, Ji[2] * Ji[2]);
+    for (int a = 0; a < 3; ++a) atomicAdd(acc + 6 + a, Ji[a] * r);
+    double* wp = d.Wpart + (size_t)c * 9;  // W_i partner block: J_i^T J_j
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) wp[a * 3 + b] = -Ji[a] * Ji[b];
+  } else {
+    const uint32_t ci = F6 + 3 * (uint32_t)qi;
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b <= a; ++b) s_add(d, ci + a, ci + b, Ji[a] * Ji[b]);
+      atomicAdd(d.hdiag + ci + a, Ji[a] * Ji[a]);
+      atomicAdd(d.gB + ci + a, Ji[a] * r);
+      // cross block J_i^T J_j = -Ji Ji^T between two different promoted points
+      for (int b = 0; b < 3; ++b) {
+        const double v = -Ji[a] * Ji[b];
+        if (ci > cj) atomicAdd(s_addr(d, ci + a, cj + b), v); else atomicAdd(s_addr(d, cj + b, ci + a), v);
+      }
+    }
+  }
+}
+
+// promoted points: the observation part of their Hessian diagonal sits in the point slab of the owning
+// rank; fold it into hdiag (so that it is all-reduced with the rest) before the Jacobi scaling is taken
+__global__ void k_promote_diag(Dev d) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= d.Q) return;
+  const uint32_t p = d.promoted_ids[q];
+  const double* acc = d.ptacc + (size_t)p * 36;
+  const uint32_t col = 6 * d.F + 3 * q;
+  atomicAdd(d.hdiag + col + 0, acc[0]); atomicAdd(d.hdiag + col + 1, acc[3]); atomicAdd(d.hdiag + col + 2, acc[5]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Jacobi scaling (ceres: 1 / (1 + sqrt(column norm^2)), fixed at iteration 0)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_jacobi(Dev d, int enabled) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < d.n_red) d.sig_red[t] = enabled ? 1.0 / (1.0 + sqrt(d.hdiag[t])) : 1.0;
+  if (t < d.P) {
+    const double* acc = d.ptacc + (size_t)t * 36;
+    d.sigP[3 * (size_t)t + 0] = enabled ? 1.0 / (1.0 + sqrt(acc[0])) : 1.0;
+    d.sigP[3 * (size_t)t + 1] = enabled ? 1.0 / (1.0 + sqrt(acc[3])) : 1.0;
+    d.sigP[3 * (size_t)t + 2] = enabled ? 1.0 / (1.0 + sqrt(acc[5])) : 1.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-point Schur complement: one wave per owned, eliminated point
+// ---------------------------------------------------------------------------------------------
+struct WBlock { const double* W; uint32_t width, ldw, base; };
+
+LIFCAL_DEV WBlock point_block(const Dev& d, uint32_t p, uint32_t bidx, uint32_t ns) {
+  WBlock b;
+  if (bidx == 0) { b.W = d.ptacc + (size_t)p * 36 + 9; b.width = d.nc; b.ldw = NCMAX; b.base = 6 * d.F + 3 * d.Q; }
+  else if (bidx <= ns) { const uint32_t s = d.pt_slot0[p] + bidx - 1; b.W = d.Wv + (size_t)s * 18; b.width = 6; b.ldw = 6; b.base = 6 * d.slot_fr[s]; }
+  else { const uint32_t c = d.pt_cons_list[d.pt_cons0[p] + (bidx - ns - 1)]; b.W = d.Wpart + (size_t)c * 9; b.width = 3; b.ldw = 3; b.base = 6 * d.F + 3 * (uint32_t)d.promoted[d.c_j[c]]; }
+  return b;
+}
+
+__global__ __launch_bounds__(256) void k_schur(Dev d, double radius) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t w = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= d.n_owned) return;
+  const uint32_t p = d.owned[w];
+  const double* acc = d.ptacc + (size_t)p * 36;
+  if (d.promoted[p] >= 0) {
+    // promoted point: its three columns belong to the reduced system (arrow rows 3q..3q+2):
+    // U -> diagonal block, g -> gradient, Wc -> camera x point block, Wv -> point x pose blocks
+    const uint32_t q = (uint32_t)d.promoted[p], F6 = 6 * d.F, col0 = F6 + 3 * q, camcol = F6 + 3 * d.Q;
+    const uint32_t ns = d.pt_nslots[p];
+    if (lane < 6) { const int ii[6] = {0, 1, 2, 1, 2, 2}, jj[6] = {0, 0, 0, 1, 1, 2}; s_add(d, col0 + ii[lane], col0 + jj[lane], acc[lane]); }
+    if (lane < 3) atomicAdd(d.gB + col0 + lane, acc[6 + lane]);
+    for (uint32_t t = lane; t < 3 * d.nc; t += 64) { const uint32_t i = t / d.nc, j = t % d.nc; s_add(d, camcol + j, col0 + i, acc[9 + i * NCMAX + j]); }
+    for (uint32_t t = lane; t < 18 * ns; t += 64) {
+      const uint32_t sidx = d.pt_slot0[p] + t / 18, e = t % 18, i = e / 6, j = e % 6;
+      s_add(d, col0 + i, 6 * d.slot_fr[sidx] + j, d.Wv[(size_t)sidx * 18 + e]);
+    }
+    return;
+  }
+  // damped point block (ceres LevenbergMarquardtStrategy: D^2 = clamp(diag(J^T J)) / radius in scaled space)
+  double U[6], lam[3];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) U[k] = acc[k];
+  const double g0 = acc[6], g1 = acc[7], g2 = acc[8];
+  {
+    const double h[3] = {U[0], U[3], U[5]};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const double s = d.sigP[3 * (size_t)p + k]; lam[k] = fmin(fmax(h[k] * s * s, d.lm_min), d.lm_max) / (radius * s * s); }
+  }
+  U[0] += lam[0]; U[3] += lam[1]; U[5] += lam[2];
+  // inverse through the Cholesky factor (ceres InvertPSDMatrix<3>)
+  double iv[9]; bool ok = true;
+  {
+    double l00 = U[0]; ok = ok && (l00 > 0.0); l00 = sqrt(l00);
+    const double l10 = U[1] / l00, l20 = U[2] / l00;
+    double l11 = U[3] - l10 * l10; ok = ok && (l11 > 0.0); l11 = sqrt(l11);
+    const double l21 = (U[4] - l20 * l10) / l11;
+    double l22 = U[5] - l20 * l20 - l21 * l21; ok = ok && (l22 > 0.0); l22 = sqrt(l22);
+    const double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+    const double m10 = -l10 * i00 * i11, m21 = -l21 * i11 * i22, m20 = -(l20 * i00 + l21 * m10) * i22;  // L^-1
+    iv[0] = i00 * i00 + m10 * m10 + m20 * m20; iv[1] = m10 * i11 + m20 * m21; iv[2] = m20 * i22;
+    iv[4] = i11 * i11 + m21 * m21;            iv[5] = m21 * i22;             iv[8] = i22 * i22;
+    iv[3] = iv[1]; iv[6] = iv[2]; iv[7] = iv[5];
+    if (!ok) { for (int k = 0; k < 9; ++k) iv[k] = 0.0; }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) d.Uinv[9 * (size_t)p + k] = iv[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) d.lamP[3 * (size_t)p + k] = lam[k];
+    if (!ok) atomicAdd(d.scal + SCAL_BAD_U, 1.0);
+    // max |g_p| for the gradient-tolerance test
+    const double gm = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
+    atomicMax((unsigned long long*)(d.scal + SCAL_GMAX0 + d.rank), (unsigned long long)__double_as_longlong(gm));
+  }
+  const double ig[3] = {iv[0] * g0 + iv[1] * g1 + iv[2] * g2, iv[3] * g0 + iv[4] * g1 + iv[5] * g2, iv[6] * g0 + iv[7] * g1 + iv[8] * g2};
+  const uint32_t ns = d.pt_nslots[p];
+  const uint32_t ncon = d.pt_cons0 ? d.pt_cons0[p + 1] - d.pt_cons0[p] : 0;
+  const uint32_t nb = 1 + ns + ncon;
+  // rhs accumulation: W^T U^-1 g
+  for (uint32_t bi = lane; bi < nb; bi += 64) {
+    const WBlock B = point_block(d, p, bi, ns);
+    for (uint32_t j = 0; j < B.width; ++j)
+      atomicAdd(d.rhsacc + B.base + j, B.W[j] * ig[0] + B.W[B.ldw + j] * ig[1] + B.W[2 * B.ldw + j] * ig[2]);
+  }
+  // S -= W^T U^-1 W over unordered block pairs
+  const uint32_t npairs = nb * (nb + 1) / 2;
+  for (uint32_t t = lane; t < npairs; t += 64) {
+    uint32_t bi = 0, rem = t;
+    while (rem >= nb - bi) { rem -= nb - bi; ++bi; }
+    const uint32_t bj = bi + rem;
+    const WBlock Bi = point_block(d, p, bi, ns), Bj = point_block(d, p, bj, ns);
+    const bool same = (bi == bj), same_base = (Bi.base == Bj.base);
+    for (uint32_t j = 0; j < Bj.width; ++j) {
+      const double w0 = Bj.W[j], w1 = Bj.W[Bj.ldw + j], w2 = Bj.W[2 * Bj.ldw + j];
+      const double y0 = iv[0] * w0 + iv[1] * w1 + iv[2] * w2, y1 = iv[3] * w0 + iv[4] * w1 + iv[5] * w2, y2 = iv[6] * w0 + iv[7] * w1 + iv[8] * w2;
+      for (uint32_t i = same ? j : 0; i < Bi.width; ++i) {
+        double m = -(Bi.W[i] * y0 + Bi.W[Bi.ldw + i] * y1 + Bi.W[2 * Bi.ldw + i] * y2);
+        if (!same && same_base && i == j) m *= 2.0;
+        s_add(d, Bi.base + i, Bj.base + j, m);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// finalize: LM diagonal on the reduced system + rhs row; identity on columns that are not solved for
+// ---------------------------------------------------------------------------------------------
+__global__ void k_finalize(Dev d, double radius) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= d.n_red) return;
+  const uint32_t F6 = 6 * d.F;
+  bool live;
+  if (t < F6) live = d.use_poses && d.frame_live[t / 6];
+  else if (t < F6 + 3 * d.Q) live = true;
+  else live = d.camc->chm[t - F6 - 3 * d.Q] != 0.0;
+  double* diag = s_addr(d, t, t);
+  double* rhs = d.Sarrow + (size_t)d.NA * d.ld;  // extra arrow row carries the right-hand side
+  if (live) {
+    const double s = d.sig_red[t];
+    const double lam = fmin(fmax(d.hdiag[t] * s * s, d.lm_min), d.lm_max) / (radius * s * s);
+    d.lam_red[t] = lam;
+    *diag += lam;
+    rhs[t] = -d.gB[t] + d.rhsacc[t];
+  } else {
+    d.lam_red[t] = 0.0;
+    *diag = 1.0;
+    rhs[t] = 0.0;
+  }
+  // max |g| over the reduced block (bit pattern of a non-negative double orders like an integer)
+  atomicMax((unsigned long long*)(d.step + ST_GMAX_RED), (unsigned long long)__double_as_longlong(fabs(d.gB[t])));
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-banded + arrow Cholesky, single workgroup (the reduced system is small and latency bound).
+// Storage: Sband[f][dd] = 6x6 block (pose f rows, pose f-dd cols); Sarrow rows (promoted | camera | rhs)
+// over columns (poses | arrow).  The rhs row makes the forward substitution part of the factorisation.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_band_chol(Dev d) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // [0,36) L_jj, [36,72) L_jj^-1, [72] fail, [80..) panel
+  double* Ld = smem; double* Li = smem + 36; double* failp = smem + 72;
+  double* panel = d.panel_g ? d.panel_g : smem + 80;  // (6*bw + NA + 1) x 6
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t F = d.F, bw = d.bw, NAx = d.NA + 1, ld = d.ld;
+  if (tid == 0) *failp = 0.0;
+  __syncthreads();
+  for (uint32_t j = 0; j < F; ++j) {
+    double* Sjj = d.Sband + (size_t)j * (bw + 1) * 36;
+    if (tid == 0) {  // 6x6 Cholesky and the inverse of its factor
+      double L[6][6];
+      for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) L[a][b] = Sjj[a * 6 + b];
+      bool ok = true;
+      for (int c = 0; c < 6; ++c) {
+        double dg = L[c][c];
+        for (int k = 0; k < c; ++k) dg -= L[c][k] * L[c][k];
+        if (!(dg > 0.0)) { ok = false; dg = 1.0; }
+        dg = sqrt(dg); L[c][c] = dg;
+        for (int r = c + 1; r < 6; ++r) { double s = L[r][c]; for (int k = 0; k < c; ++k) s -= L[r][k] * L[c][k]; L[r][c] = s / dg; }
+      }
+      if (!ok) *failp = 1.0;
+      double I[6][6];
+      for (int c = 0; c < 6; ++c) {  // columns of L^-1
+        for (int r = 0; r < 6; ++r) I[r][c] = 0.0;
+        I[c][c] = 1.0 / L[c][c];
+        for (int r = c + 1; r < 6; ++r) { double s = 0.0; for (int k = c; k < r; ++k) s -= L[r][k] * I[k][c]; I[r][c] = s / L[r][r]; }
+      }
+      for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { Ld[a * 6 + b] = (b <= a) ? L[a][b] : 0.0; Li[a * 6 + b] = (b <= a) ? I[a][b] : 0.0; }
+      for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) Sjj[a * 6 + b] = L[a][b];
+      for (int k = 0; k < 36; ++k) d.Linv[(size_t)j * 36 + k] = Li[k];
+    }
+    __syncthreads();
+    // panel rows: band rows of blocks (i, i-j) for i in (j, min(j+bw, F-1)], then the arrow rows
+    const uint32_t nbel = min(bw, F - 1 - j);
+    const uint32_t nrows = 6 * nbel + NAx;
+    for (uint32_t r = tid; r < nrows; r += nt) {
+      double* src;
+      if (r < 6 * nbel) { const uint32_t i = j + 1 + r / 6; src = d.Sband + ((size_t)i * (bw + 1) + (i - j)) * 36 + (r % 6) * 6; }
+      else src = d.Sarrow + (size_t)(r - 6 * nbel) * ld + 6 * j;
+      double x[6], y[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = src[k];
+#pragma unroll
+      for (int c = 0; c < 6; ++c) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k <= c; ++k) s += x[k] * Li[c * 6 + k];
+        y[c] = s; }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { src[k] = y[k]; panel[(size_t)r * 6 + k] = y[k]; }
+    }
+    __syncthreads();
+    // trailing update: S(r, c) -= panel[r] . panel[c] for c <= r (only c inside the band / arrow)
+    const uint32_t nb6 = 6 * nbel;
+    const uint64_t nband = (uint64_t)nb6 * (nb6 + 1) / 2;
+    const uint64_t narrow = (uint64_t)NAx * nb6;
+    const uint64_t naa = (uint64_t)NAx * (NAx + 1) / 2;
+    for (uint64_t t = tid; t < nband + narrow + naa; t += nt) {
+      uint32_t r, cidx; double* dst;
+      if (t < nband) {
+        r = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+        while ((uint64_t)r * (r + 1) / 2 > t) --r;
+        while ((uint64_t)(r + 1) * (r + 2) / 2 <= t) ++r;
+        cidx = (uint32_t)(t - (uint64_t)r * (r + 1) / 2);
+        const uint32_t bi = j + 1 + r / 6, bc = j + 1 + cidx / 6;
+        dst = d.Sband + ((size_t)bi * (bw + 1) + (bi - bc)) * 36 + (r % 6) * 6 + (cidx % 6);
+      } else if (t < nband + narrow) {
+        const uint64_t u = t - nband; const uint32_t a = (uint32_t)(u / nb6); cidx = (uint32_t)(u % nb6); r = nb6 + a;
+        dst = d.Sarrow + (size_t)a * ld + 6 * (j + 1) + cidx;
+      } else {
+        const uint64_t u = t - nband - narrow;
+        uint32_t a = (uint32_t)((sqrt(8.0 * (double)u + 1.0) - 1.0) * 0.5);
+        while ((uint64_t)a * (a + 1) / 2 > u) --a;
+        while ((uint64_t)(a + 1) * (a + 2) / 2 <= u) ++a;
+        const uint32_t b = (uint32_t)(u - (uint64_t)a * (a + 1) / 2);
+        r = nb6 + a; cidx = nb6 + b;
+        dst = d.Sarrow + (size_t)a * ld + 6 * F + b;
+      }
+      const double* pr = panel + (size_t)r * 6; const double* pc = panel + (size_t)cidx * 6;
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) s += pr[k] * pc[k];
+      *dst -= s;
+    }
+    __syncthreads();
+  }
+  // dense Cholesky of the arrow block (NA x NA) with the rhs row carried along
+  double* Aa = d.Sarrow + 6 * F;  // Aa[a*ld + b]
+  for (uint32_t c = 0; c < d.NA; ++c) {
+    if (tid == 0) { double dg = Aa[(size_t)c * ld + c]; if (!(dg > 0.0)) { *failp = 1.0; dg = 1.0; } Aa[(size_t)c * ld + c] = sqrt(dg); }
+    __syncthreads();
+    const double dg = Aa[(size_t)c * ld + c];
+    for (uint32_t r = c + 1 + tid; r < NAx; r += nt) Aa[(size_t)r * ld + c] /= dg;
+    __syncthreads();
+    const uint32_t m = NAx - c - 1;
+    for (uint64_t t = tid; t < (uint64_t)m * (m + 1) / 2; t += nt) {
+      uint32_t a = (uint32_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+      while ((uint64_t)a * (a + 1) / 2 > t) --a;
+      while ((uint64_t)(a + 1) * (a + 2) / 2 <= t) ++a;
+      const uint32_t b = (uint32_t)(t - (uint64_t)a * (a + 1) / 2);
+      const uint32_t r = c + 1 + a, cc2 = c + 1 + b;
+      Aa[(size_t)r * ld + cc2] -= Aa[(size_t)r * ld + c] * Aa[(size_t)cc2 * ld + c];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) d.step[ST_CHOL_FAIL] = *failp;
+}
+
+// backward substitution L^T x = y (y sits in the rhs arrow row), single workgroup
+__global__ __launch_bounds__(1024) void k_band_backsolve(Dev d) {
+  const uint32_t tid = threadIdx.x, nt = blockDim.x;
+  const uint32_t F = d.F, bw = d.bw, NA = d.NA, ld = d.ld;
+  double* x = d.delta_red;
+  const double* y = d.Sarrow + (size_t)NA * ld;
+  const double* Aa = d.Sarrow + 6 * F;
+  __shared__ double acc6[6];
+  for (uint32_t k = tid; k < d.n_red; k += nt) x[k] = y[k];
+  __syncthreads();
+  // arrow part (dense, lower factor Aa): x_a = (y_a - sum_{b>a} L[b][a] x_b) / L[a][a]
+  for (int a = (int)NA - 1; a >= 0; --a) {
+    if (tid == 0) x[6 * F + a] /= Aa[(size_t)a * ld + a];
+    __syncthreads();
+    const double xa = x[6 * F + a];
+    for (uint32_t b = tid; b < (uint32_t)a; b += nt) x[6 * F + b] -= Aa[(size_t)a * ld + b] * xa;
+    __syncthreads();
+  }
+  // pose blocks, last to first: x_j = L_jj^-T (y_j - sum_{i>j} L_ij^T x_i - sum_a L_aj^T x_a)
+  for (int j = (int)F - 1; j >= 0; --j) {
+    if (tid < 6) acc6[tid] = 0.0;
+    __syncthreads();
+    const uint32_t nbel = min(bw, F - 1 - (uint32_t)j);
+    const uint32_t nrows = 6 * nbel + NA;
+    // each thread handles one (row, k) product chain: 6 partial sums via LDS atomics on a tiny array
+    for (uint32_t r = tid; r < nrows; r += nt) {
+      const double* src; double xv;
+      if (r < 6 * nbel) { const uint32_t i = (uint32_t)j + 1 + r / 6; src = d.Sband + ((size_t)i * (bw + 1) + (i - j)) * 36 + (r % 6) * 6; xv = x[6 * i + r % 6]; }
+      else { const uint32_t a = r - 6 * nbel; src = d.Sarrow + (size_t)a * ld + 6 * j; xv = x[6 * F + a]; }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) atomicAdd(&acc6[k], src[k] * xv);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      const double* Li = d.Linv + (size_t)j * 36;
+      double t6[6], o[6];
+      for (int k = 0; k < 6; ++k) t6[k] = x[6 * j + k] - acc6[k];
+      for (int c = 0; c < 6; ++c) { double s = 0.0; for (int k = c; k < 6; ++k) s += Li[k * 6 + c] * t6[k]; o[c] = s; }  // L^-T t
+      for (int k = 0; k < 6; ++k) x[6 * j + k] = o[k];
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step application
+// ---------------------------------------------------------------------------------------------
+// camera + poses + promoted points: candidate = Plus(x, delta) with box projection (ceres ParameterBlock::Plus)
+__global__ void k_update_reduced(Dev d) {
+  __shared__ double red[4];
+  if (threadIdx.x < 4) red[threadIdx.x] = 0.0;
+  __syncthreads();
+  const uint32_t F6 = 6 * d.F, camcol = F6 + 3 * d.Q;
+  double gtd = 0.0, ddd = 0.0, st2 = 0.0, x2 = 0.0;
+  for (uint32_t t = threadIdx.x; t < d.n_red; t += blockDim.x) {
+    const double dl = d.delta_red[t];
+    gtd += d.gB[t] * dl; ddd += d.lam_red[t] * dl * dl;
+    if (t < F6) {
+      const double xo = d.views[t], xn = xo + dl;
+      d.views_c[t] = xn;
+      if (d.use_poses && d.frame_live[t / 6]) { st2 += (xn - xo) * (xn - xo); x2 += xo * xo; }
+    } else if (t < camcol) {
+      const uint32_t q = (t - F6) / 3, k = (t - F6) % 3;
+      (void)q; (void)k;  // promoted points are written by k_backsub (it knows the point id)
+    }
+  }
+  for (uint32_t j = threadIdx.x; j < LIFCAL_BA_MAX_CAMERA_PARAMETERS; j += blockDim.x) {
+    const double xo = d.cam[j];
+    double xn = xo;
+    if (j < d.nc && d.camc->chm[j] != 0.0) xn = xo + d.delta_red[camcol + j];
+    if (d.lower && xn < d.lower[j]) xn = d.lower[j];
+    if (d.upper && xn > d.upper[j]) xn = d.upper[j];
+    d.cam_c[j] = xn;
+    st2 += (xn - xo) * (xn - xo); x2 += xo * xo;
+  }
+  atomicAdd(&red[0], gtd); atomicAdd(&red[1], ddd); atomicAdd(&red[2], st2); atomicAdd(&red[3], x2);
+  __syncthreads();
+  if (threadIdx.x == 0) { d.step[ST_GTD] += red[0]; d.step[ST_DDD] += red[1]; d.step[ST_STEP2] += red[2]; d.step[ST_X2] += red[3]; }
+}
+
+// points: delta_P = -U^-1 (g_p + W_p delta_B) for eliminated points, reduced solution for promoted ones
+__global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by the host side */) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  double gtd = 0.0, ddd = 0.0, st2 = 0.0, x2 = 0.0;
+  if (t < d.n_owned) {
+    const uint32_t p = d.owned[t];
+    if (d.promoted[p] < 0) {
+      const double* acc = d.ptacc + (size_t)p * 36;
+      double v[3] = {acc[6], acc[7], acc[8]};
+      const uint32_t ns = d.pt_nslots[p];
+      const uint32_t ncon = d.pt_cons0 ? d.pt_cons0[p + 1] - d.pt_cons0[p] : 0;
+      for (uint32_t bi = 0; bi < 1 + ns + ncon; ++bi) {
+        const WBlock B = point_block(d, p, bi, ns);
+        for (uint32_t j = 0; j < B.width; ++j) {
+          const double dl = d.delta_red[B.base + j];
+          v[0] += B.W[j] * dl; v[1] += B.W[B.ldw + j] * dl; v[2] += B.W[2 * B.ldw + j] * dl;
+        }
+      }
+      const double* iv = d.Uinv + 9 * (size_t)p;
+      for (int k = 0; k < 3; ++k) {
+        const double dl = -(iv[3 * k] * v[0] + iv[3 * k + 1] * v[1] + iv[3 * k + 2] * v[2]);
+        const double xo = d.pts[3 * (size_t)p + k];
+        d.pts_c[3 * (size_t)p + k] = xo + dl;
+        gtd += acc[6 + k] * dl; ddd += d.lamP[3 * (size_t)p + k] * dl * dl; st2 += dl * dl; x2 += xo * xo;
+      }
+    }
+  }
+  // promoted points are replicated: every rank applies the same reduced step; rank 0 accounts for the norms
+  if (t < d.Q) {
+    const uint32_t F6 = 6 * d.F;
+    const uint32_t pid = d.promoted_ids[t];
+    for (int k = 0; k < 3; ++k) {
+      const double dl = d.delta_red[F6 + 3 * t + k];
+      const double xo = d.pts[3 * (size_t)pid + k];
+      d.pts_c[3 * (size_t)pid + k] = xo + dl;
+      if (d.rank == 0) { st2 += dl * dl; x2 += xo * xo; }
+    }
+  }
+  gtd = wave_sum(gtd); ddd = wave_sum(ddd); st2 = wave_sum(st2); x2 = wave_sum(x2);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(partial + 0, gtd); atomicAdd(partial + 1, ddd); atomicAdd(partial + 2, st2); atomicAdd(partial + 3, x2); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// cost at the candidate point (values only), optional directional derivative for the line search
+// ---------------------------------------------------------------------------------------------
+template <int NR, bool TAN, bool ADJ>
+__global__ __launch_bounds__(256) void k_cost(Dev d, const CamConsts* camc, const double* ft_tab, const double* lt_tab,
+                                              const double* pts, double* cost_out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+  const CamConsts c = *camc;
+  double cost = 0.0;
+  for (uint32_t tile = wave; tile < d.n_tiles; tile += n_waves) {
+    const uint32_t slot = tile * 64 + lane;
+    const uint32_t cnt = d.slot_cnt[slot];
+    const uint32_t row0 = d.tile_row0[tile], kmax = d.tile_row0[tile + 1] - row0;
+    const double* ft = ft_tab + (size_t)d.slot_fr[slot] * FRAME_STRIDE;
+    const double* P = pts + 3 * (size_t)d.slot_pt[slot];
+    GroupConsts g;
+    {
+      const double P0 = P[0], P1 = P[1], P2 = P[2];
+      const double X = ft[0] * P0 + ft[1] * P1 + ft[2] * P2 + ft[9];
+      const double Y = ft[3] * P0 + ft[4] * P1 + ft[5] * P2 + ft[10];
+      const double Z = ft[6] * P0 + ft[7] * P1 + ft[8] * P2 + ft[11];
+      group_prepare(c, X, Y, Z, g);
+    }
+    for (uint32_t k = 0; k < kmax; ++k) {
+      if (k < cnt) {
+        const size_t at = ((size_t)row0 + k) * 64 + lane;
+        const double* L = lt_tab + (size_t)d.ell_lens[at] * LENS_STRIDE;
+        double rx, ry;
+        obs_value<NR, TAN, ADJ>(c, g, L[0], L[1], L[2], L[3], d.ell_u[at], d.ell_v[at], rx, ry);
+        const double sq = rx * rx + ry * ry;
+        cost += d.robust ? 0.5 * c.loss_b * log(1.0 + sq * c.loss_c) : 0.5 * sq;
+      }
+    }
+  }
+  cost = wave_sum(cost);
+  if (lane == 0) atomicAdd(cost_out, cost);
+}
+
+// reprojection statistics (reference src/CameraCalibration.cpp:1026-1103): out = {sum ex^2, sum ey^2, n, inliers}, max as bits
+template <int NR, bool TAN, bool ADJ>
+__global__ __launch_bounds__(256) void k_stats(Dev d, const CamConsts* camc, const double* ft_tab, const double* lt_tab,
+                                               const double* pts, double thr2, double* sums, unsigned long long* maxbits) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+  const CamConsts c = *camc;
+  double sx = 0.0, sy = 0.0, n = 0.0, inl = 0.0, mx = 0.0, my = 0.0;
+  for (uint32_t tile = wave; tile < d.n_tiles; tile += n_waves) {
+    const uint32_t slot = tile * 64 + lane;
+    const uint32_t cnt = d.slot_cnt[slot];
+    const uint32_t row0 = d.tile_row0[tile], kmax = d.tile_row0[tile + 1] - row0;
+    const double* ft = ft_tab + (size_t)d.slot_fr[slot] * FRAME_STRIDE;
+    const double* P = pts + 3 * (size_t)d.slot_pt[slot];
+    GroupConsts g;
+    {
+      const double P0 = P[0], P1 = P[1], P2 = P[2];
+      group_prepare(c, ft[0] * P0 + ft[1] * P1 + ft[2] * P2 + ft[9], ft[3] * P0 + ft[4] * P1 + ft[5] * P2 + ft[10],
+                    ft[6] * P0 + ft[7] * P1 + ft[8] * P2 + ft[11], g);
+    }
+    for (uint32_t k = 0; k < kmax; ++k) {
+      if (k < cnt) {
+        const size_t at = ((size_t)row0 + k) * 64 + lane;
+        const double* L = lt_tab + (size_t)d.ell_lens[at] * LENS_STRIDE;
+        double ex, ey;
+        obs_value<NR, TAN, ADJ>(c, g, L[0], L[1], L[2], L[3], d.ell_u[at], d.ell_v[at], ex, ey);
+        sx += ex * ex; sy += ey * ey; n += 1.0;
+        if (ex * ex + ey * ey <= thr2) inl += 1.0;
+        mx = fmax(mx, fabs(ex)); my = fmax(my, fabs(ey));
+      }
+    }
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); n = wave_sum(n); inl = wave_sum(inl);
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { mx = fmax(mx, __shfl_xor(mx, m, 64)); my = fmax(my, __shfl_xor(my, m, 64)); }
+  if (lane == 0) {
+    atomicAdd(sums + 0, sx); atomicAdd(sums + 1, sy); atomicAdd(sums + 2, n); atomicAdd(sums + 3, inl);
+    atomicMax(maxbits + 0, (unsigned long long)__double_as_longlong(mx));
+    atomicMax(maxbits + 1, (unsigned long long)__double_as_longlong(my));
+  }
+}
+
+}  // namespace lifcal

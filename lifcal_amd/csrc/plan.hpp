@@ -1,0 +1,233 @@
+// plan.hpp — host-side marshalling of LiFCal's bundle-adjustment problem into the HBM layout.
+//
+// Replaces the residual-block construction loop of the reference
+// (src/CameraCalibration.cpp:859-914: one heap-allocated functor + AutoDiffCostFunction + loss per
+// micro-image observation, frame-major) by a one-off re-ordering:
+//   * observations are sorted point-major, then by frame; every (point, frame) run is a "group"
+//     (the ~6 micro images that see one 3D point in one frame share pose, point and camera-frame
+//     coordinates, so one GPU lane walks one group);
+//   * 64 consecutive groups form a "tile" (one wavefront); observation payload is stored per tile
+//     as [k][lane] ("ELL"), so a wave's loads of step k are fully coalesced;
+//   * micro-lens centres are de-duplicated into a lens table (the 10-sweep undistortion of
+//     reference src/CameraModel.h:92-125 depends on the lens and the camera only);
+//   * points are ordered by the first frame that sees them; ranks own contiguous ranges of that
+//     order balanced by observation count;
+//   * points named as pointID_2 of a distance constraint (reference :916-925) are "promoted" into
+//     the reduced system so that the eliminated point blocks stay independent.
+// Pure host C++ (no HIP), so the CPU test-suite can exercise it through lifcal_ba_plan().
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <numeric>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/lifcal_ba.h"
+
+namespace lifcal {
+
+struct Plan {
+  // problem sizes
+  uint32_t F = 0, P = 0, N = 0, M = 0;
+  int rank = 0, world = 1;
+  // config
+  uint32_t config = 0;
+  int n_radial = 0; bool tangential = false, refine_poses = false, robust = false, refine_points = false, adj = false;
+  int nc = 5;                       // live camera slots 5 + nRad + 2*tan
+  bool use_poses = false, use_points = false, use_constraints = false;
+  // point bookkeeping (global ids)
+  std::vector<uint32_t> point_order;   // rank in the (first frame, id) order -> point id
+  std::vector<int32_t> owner;          // per point: owning rank (-1: not observed / unused)
+  std::vector<int32_t> promoted;       // per point: arrow index q or -1
+  std::vector<uint32_t> promoted_ids;
+  std::vector<uint8_t> frame_used, point_used;
+  uint32_t Q = 0;                      // number of promoted points
+  uint32_t bw = 0;                     // block bandwidth: max over points of (last frame - first frame)
+  uint32_t NA = 0;                     // arrow rows: 3Q + nc
+  uint32_t n_red_int = 0;              // 6F + NA  (internal ordering: poses | promoted | camera)
+  uint32_t n_red_canon = 0;            // 17 + 6F + 3Q (canonical ordering of the C ABI)
+  // local (this rank) observation layout
+  uint32_t n_obs_local = 0, n_groups = 0, n_tiles = 0, n_slots = 0, max_group_obs = 0;
+  std::vector<uint32_t> obs_order;     // sorted position -> input index (local obs only)
+  std::vector<uint32_t> slot_pt, slot_fr, slot_cnt;   // per slot (tile*64+lane); cnt 0 = idle lane
+  std::vector<uint32_t> tile_row0;     // n_tiles+1: first 64-wide row of each tile in the ELL payload
+  std::vector<double> ell_u, ell_v;    // rows*64
+  std::vector<uint32_t> ell_lens;      // rows*64
+  std::vector<uint32_t> ell_src;       // rows*64: input index of the observation (UINT32_MAX = padding)
+  // per point: its slots are contiguous [pt_slot0[p], pt_slot0[p]+pt_nslots[p])
+  std::vector<uint32_t> pt_slot0, pt_nslots;
+  std::vector<uint32_t> owned_points;  // points this rank owns (observed or constrained), in point_order
+  // lenses
+  std::vector<double> lens_xy;         // 2 per lens
+  uint32_t n_lenses = 0;
+  // constraints (global ids); processed by the rank owning c_i's point
+  std::vector<uint32_t> c_i, c_j; std::vector<double> c_dist, c_sigma;
+  std::vector<uint32_t> my_constraints;          // indices into c_*
+  std::vector<uint32_t> pt_cons0, pt_cons_list;  // CSR over points: constraints in which the point is c_i and eliminated
+};
+
+inline int plan_validate(const lifcal_ba_problem* p) {
+  if (!p || !p->cam) return LIFCAL_BA_ERR_INVALID_ARG;
+  if (p->n_obs && (!p->u || !p->v || !p->mcx || !p->mcy || !p->pt || !p->fr)) return LIFCAL_BA_ERR_INVALID_ARG;
+  if ((p->n_frames && !p->views) || (p->n_points && !p->pts)) return LIFCAL_BA_ERR_INVALID_ARG;
+  if (!(p->scale > 0.0) || !(p->spx > 0.0) || !(p->spy > 0.0)) return LIFCAL_BA_ERR_INVALID_ARG;
+  for (uint32_t i = 0; i < p->n_obs; ++i)
+    if (p->pt[i] >= p->n_points || p->fr[i] >= p->n_frames) return LIFCAL_BA_ERR_OUT_OF_RANGE;
+  if (p->n_constraints && p->use_constraints) {
+    if (!p->c_i || !p->c_j || !p->c_dist || !p->c_sigma) return LIFCAL_BA_ERR_INVALID_ARG;
+    for (uint32_t c = 0; c < p->n_constraints; ++c) {
+      if (p->c_i[c] >= p->n_points || p->c_j[c] >= p->n_points) return LIFCAL_BA_ERR_OUT_OF_RANGE;
+      if (p->c_i[c] == p->c_j[c]) return LIFCAL_BA_ERR_INVALID_ARG;
+    }
+  }
+  return 0;
+}
+
+inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl) {
+  if (int rc = plan_validate(p)) return rc;
+  if (world < 1 || rank < 0 || rank >= world) return LIFCAL_BA_ERR_INVALID_ARG;
+  Plan& L = *pl;
+  L.F = p->n_frames; L.P = p->n_points; L.N = p->n_obs; L.M = p->n_constraints;
+  L.rank = rank; L.world = world; L.config = p->config;
+  L.n_radial = p->config & 3; L.tangential = (p->config & LIFCAL_BA_CFG_TANGENTIAL) != 0;
+  L.refine_poses = (p->config & LIFCAL_BA_CFG_REFINE_POSES) != 0;
+  L.robust = (p->config & LIFCAL_BA_CFG_ROBUST) != 0;
+  L.refine_points = (p->config & LIFCAL_BA_CFG_REFINE_POINTS) != 0;
+  L.adj = (p->config & LIFCAL_BA_CFG_ML_CENTER_ADJ) != 0;
+  L.nc = 5 + L.n_radial + (L.tangential ? 2 : 0);
+  L.use_poses = L.refine_poses;
+  L.use_points = L.refine_poses && L.refine_points;  // reference :879-912: points are blocks only in <2,17,6,3>
+  L.use_constraints = L.use_points && p->use_constraints && p->n_constraints > 0;
+
+  // --- per point: first / last frame, observation count ---
+  std::vector<uint32_t> first(L.P, UINT32_MAX), last(L.P, 0), cnt(L.P, 0);
+  L.frame_used.assign(L.F, 0); L.point_used.assign(L.P, 0);
+  for (uint32_t i = 0; i < L.N; ++i) {
+    const uint32_t q = p->pt[i], f = p->fr[i];
+    first[q] = std::min(first[q], f); last[q] = std::max(last[q], f); cnt[q]++;
+    L.frame_used[f] = 1; L.point_used[q] = 1;
+  }
+  L.bw = 0;
+  for (uint32_t q = 0; q < L.P; ++q) if (cnt[q]) L.bw = std::max(L.bw, last[q] - first[q]);
+
+  // --- constraints / promotion ---
+  L.promoted.assign(L.P, -1); L.promoted_ids.clear();
+  L.c_i.clear(); L.c_j.clear(); L.c_dist.clear(); L.c_sigma.clear();
+  if (L.use_constraints) {
+    std::vector<uint8_t> flag(L.P, 0);
+    for (uint32_t c = 0; c < L.M; ++c) {
+      L.c_i.push_back(p->c_i[c]); L.c_j.push_back(p->c_j[c]); L.c_dist.push_back(p->c_dist[c]); L.c_sigma.push_back(p->c_sigma[c]);
+      flag[p->c_j[c]] = 1; L.point_used[p->c_i[c]] = 1; L.point_used[p->c_j[c]] = 1;
+    }
+    for (uint32_t q = 0; q < L.P; ++q) if (flag[q]) { L.promoted[q] = (int32_t)L.promoted_ids.size(); L.promoted_ids.push_back(q); }
+  }
+  L.Q = (uint32_t)L.promoted_ids.size();
+  L.NA = 3 * L.Q + (uint32_t)L.nc;
+  L.n_red_int = 6 * L.F + L.NA;
+  L.n_red_canon = LIFCAL_BA_MAX_CAMERA_PARAMETERS + 6 * L.F + 3 * L.Q;
+
+  // --- point order and ownership ---
+  L.point_order.resize(L.P);
+  std::iota(L.point_order.begin(), L.point_order.end(), 0u);
+  std::stable_sort(L.point_order.begin(), L.point_order.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
+  L.owner.assign(L.P, -1);
+  {
+    const uint64_t total = L.N;
+    uint64_t acc = 0;
+    for (uint32_t r = 0; r < L.P; ++r) {
+      const uint32_t q = L.point_order[r];
+      if (!L.point_used[q]) continue;
+      // rank k owns the points whose running observation count falls in [k, k+1) * total / world
+      int o = total ? (int)std::min<uint64_t>((uint64_t)world - 1, acc * (uint64_t)world / std::max<uint64_t>(total, 1)) : 0;
+      L.owner[q] = o;
+      acc += cnt[q];
+    }
+  }
+  L.owned_points.clear();
+  for (uint32_t r = 0; r < L.P; ++r) { const uint32_t q = L.point_order[r]; if (L.owner[q] == rank) L.owned_points.push_back(q); }
+
+  // --- local observations sorted by (point order, frame) ---
+  std::vector<uint32_t> order_rank(L.P, 0);
+  for (uint32_t r = 0; r < L.P; ++r) order_rank[L.point_order[r]] = r;
+  L.obs_order.clear();
+  for (uint32_t i = 0; i < L.N; ++i) if (L.owner[p->pt[i]] == rank) L.obs_order.push_back(i);
+  std::stable_sort(L.obs_order.begin(), L.obs_order.end(), [&](uint32_t a, uint32_t b) {
+    const uint32_t ra = order_rank[p->pt[a]], rb = order_rank[p->pt[b]];
+    if (ra != rb) return ra < rb;
+    return p->fr[a] < p->fr[b];
+  });
+  L.n_obs_local = (uint32_t)L.obs_order.size();
+
+  // --- lenses: exact-bit de-duplication of (mcx, mcy) over the local observations ---
+  struct Key { uint64_t a, b; bool operator==(const Key& o) const { return a == o.a && b == o.b; } };
+  struct KeyHash { size_t operator()(const Key& k) const { return (size_t)(k.a * 0x9E3779B97F4A7C15ull ^ (k.b + 0x7F4A7C15ull + (k.a << 6))); } };
+  std::unordered_map<Key, uint32_t, KeyHash> lens_map;
+  lens_map.reserve(1 << 16);
+  std::vector<uint32_t> obs_lens(L.n_obs_local);
+  L.lens_xy.clear();
+  for (uint32_t s = 0; s < L.n_obs_local; ++s) {
+    const uint32_t i = L.obs_order[s];
+    Key k; std::memcpy(&k.a, &p->mcx[i], 8); std::memcpy(&k.b, &p->mcy[i], 8);
+    auto it = lens_map.find(k);
+    if (it == lens_map.end()) { it = lens_map.emplace(k, (uint32_t)(L.lens_xy.size() / 2)).first; L.lens_xy.push_back(p->mcx[i]); L.lens_xy.push_back(p->mcy[i]); }
+    obs_lens[s] = it->second;
+  }
+  L.n_lenses = (uint32_t)(L.lens_xy.size() / 2);
+
+  // --- groups (runs of equal (point, frame)) -> slots -> tiles ---
+  struct Group { uint32_t pt, fr, s0, n; };
+  std::vector<Group> groups;
+  for (uint32_t s = 0; s < L.n_obs_local;) {
+    const uint32_t i = L.obs_order[s];
+    uint32_t e = s + 1;
+    while (e < L.n_obs_local && p->pt[L.obs_order[e]] == p->pt[i] && p->fr[L.obs_order[e]] == p->fr[i]) ++e;
+    groups.push_back({p->pt[i], p->fr[i], s, e - s});
+    s = e;
+  }
+  L.n_groups = (uint32_t)groups.size();
+  L.n_tiles = (L.n_groups + 63) / 64;
+  L.n_slots = L.n_tiles * 64;
+  L.slot_pt.assign(L.n_slots, 0); L.slot_fr.assign(L.n_slots, 0); L.slot_cnt.assign(L.n_slots, 0);
+  L.tile_row0.assign(L.n_tiles + 1, 0);
+  L.max_group_obs = 0;
+  for (uint32_t t = 0; t < L.n_tiles; ++t) {
+    uint32_t kmax = 0;
+    for (uint32_t l = 0; l < 64; ++l) { const uint32_t g = t * 64 + l; if (g < L.n_groups) kmax = std::max(kmax, groups[g].n); }
+    L.tile_row0[t + 1] = L.tile_row0[t] + kmax;
+    L.max_group_obs = std::max(L.max_group_obs, kmax);
+  }
+  const size_t rows = L.tile_row0[L.n_tiles];
+  L.ell_u.assign(rows * 64, 0.0); L.ell_v.assign(rows * 64, 0.0);
+  L.ell_lens.assign(rows * 64, 0); L.ell_src.assign(rows * 64, UINT32_MAX);
+  L.pt_slot0.assign(L.P, 0); L.pt_nslots.assign(L.P, 0);
+  for (uint32_t g = 0; g < L.n_groups; ++g) {
+    const Group& G = groups[g];
+    const uint32_t t = g / 64, l = g % 64;
+    L.slot_pt[g] = G.pt; L.slot_fr[g] = G.fr; L.slot_cnt[g] = G.n;
+    if (L.pt_nslots[G.pt] == 0) L.pt_slot0[G.pt] = g;
+    L.pt_nslots[G.pt]++;
+    for (uint32_t k = 0; k < G.n; ++k) {
+      const size_t at = ((size_t)L.tile_row0[t] + k) * 64 + l;
+      const uint32_t i = L.obs_order[G.s0 + k];
+      L.ell_u[at] = p->u[i]; L.ell_v[at] = p->v[i]; L.ell_lens[at] = obs_lens[G.s0 + k]; L.ell_src[at] = i;
+    }
+  }
+
+  // --- constraints owned by this rank; CSR of partner columns per eliminated point ---
+  L.my_constraints.clear();
+  L.pt_cons0.assign(L.P + 1, 0); L.pt_cons_list.clear();
+  if (L.use_constraints) {
+    for (uint32_t c = 0; c < L.M; ++c) if (L.owner[L.c_i[c]] == rank || (L.owner[L.c_i[c]] < 0 && rank == 0)) L.my_constraints.push_back(c);
+    for (uint32_t c : L.my_constraints) if (L.promoted[L.c_i[c]] < 0) L.pt_cons0[L.c_i[c] + 1]++;
+    for (uint32_t q = 0; q < L.P; ++q) L.pt_cons0[q + 1] += L.pt_cons0[q];
+    L.pt_cons_list.resize(L.pt_cons0[L.P]);
+    std::vector<uint32_t> fill(L.pt_cons0.begin(), L.pt_cons0.end() - 1);
+    for (uint32_t c : L.my_constraints) if (L.promoted[L.c_i[c]] < 0) L.pt_cons_list[fill[L.c_i[c]]++] = c;
+    // a point that is only constrained (never observed) still needs an owner
+    for (uint32_t c = 0; c < L.M; ++c) if (L.owner[L.c_i[c]] < 0) { L.owner[L.c_i[c]] = 0; if (rank == 0) L.owned_points.push_back(L.c_i[c]); }
+  }
+  return 0;
+}
+
+}  // namespace lifcal
