@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""bench.py — micro-image observations/second through one Jacobian+Schur sweep (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one lifcal_ba sweep (tables + residual/Jacobian/robust-weight accumulation + point-block
+elimination + reduced system) over observations already resident in HBM.
+N = 1: the 1.0 M-observation metric point (334 frames, 20 700 points, window 10, config 0xF06, fp64).
+N > 1: weak scaling, one process per GPU (torch.distributed.run), rank r owns the r-th copy of the
+metric scene along the trajectory (334 N frames, 20 700 N points in total, sharded by 3D point by the
+library); the only data-path exchange is one RCCL sum all-reduce of the reduced normal equations per sweep.
+Rank 0 prints ONE JSON line.  `value` is whole-job obs/s; `roofline` prices the dominant kernel
+against the 8 TB/s HBM peak with the algorithmic bytes of DESIGN.md; `cpu_baseline` times the CPU
+restatement (oracle/, kind "port") on a bounded sample of the same workload on this host's cores.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
+
+
+def tiled_problem(sc, copies):
+    """`copies` disjoint copies of the scene along the trajectory sharing one camera block."""
+    from lifcal_amd import _capi as capi
+    F, P = sc.spec.n_frames, sc.spec.n_points
+    cat = lambda a: np.concatenate([a] * copies)
+    pt = np.concatenate([sc.pt.astype(np.uint32) + np.uint32(c * P) for c in range(copies)])
+    fr = np.concatenate([sc.fr.astype(np.uint32) + np.uint32(c * F) for c in range(copies)])
+    return capi.ProblemArrays(cat(sc.u), cat(sc.v), cat(sc.mcx), cat(sc.mcy), pt, fr, sc.cam0, cat(sc.views0), cat(sc.pts0),
+                              sc.spx, sc.scale, sc.config, use_constraints=0)
+
+
+def algorithmic_bytes(n_obs, n_points, n_frames, n_red):
+    """B_alg = N*40 + 2*(24 P + 48 F + 8*17) + 8*n_red(n_red+1)/2 + 8*n_red  (fp64)."""
+    return n_obs * 40 + 2 * (24 * n_points + 48 * n_frames + 8 * 17) + 8 * (n_red * (n_red + 1) // 2) + 8 * n_red
+
+
+def accumulate_kernel_bytes(n_obs, n_points, n_frames):
+    """share of B_alg the dominant kernel (k_sweep) must move: the observation stream + one parameter read."""
+    return n_obs * 40 + (24 * n_points + 48 * n_frames + 8 * 17)
+
+
+def cpu_baseline(sample_name="cfg3"):
+    import oracle
+    from lifcal_amd import _capi as capi, scene
+    sc = scene.make_scene(scene.baseline_spec(sample_name))
+    pa = capi.ProblemArrays.from_scene(sc)
+    threads = max(1, min(oracle.hardware_threads(), len(os.sched_getaffinity(0))))
+    oracle.sweep(pa, radius=1e4, threads=threads, want_matrices=False)  # warm-up (page faults, thread start)
+    best = None
+    t_end = time.time() + 20.0
+    reps = 0
+    while reps < 3 or (time.time() < t_end and reps < 12):
+        r = oracle.sweep(pa, radius=1e4, threads=threads, want_matrices=False)
+        best = r.seconds if best is None else min(best, r.seconds)
+        reps += 1
+    return {"value": sc.n_obs / best, "unit": "obs/s", "cores": threads, "kind": "port",
+            "sample": f"{sample_name}: {sc.spec.n_frames} frames, {sc.spec.n_points} points, {sc.n_obs} obs, config {sc.config:#x}; "
+                      f"dual-number Jacobian + dense Schur sweep, best of {reps}"}
+
+
+def load_traffic(workload):
+    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        return t.get(workload, {}).get("k_sweep_hbm_bytes")
+    except Exception:
+        return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="metric")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from lifcal_amd import BundleAdjustment, _capi as capi, scene, comm_unique_id
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the bundle-adjustment path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    spec = scene.baseline_spec(args.workload)
+    sc = scene.make_scene(spec)
+    pa = tiled_problem(sc, world) if world > 1 else capi.ProblemArrays.from_scene(sc)
+    n_obs_total = int(pa.struct.n_obs)
+    o = capi.default_options_py()
+    o.device = local_rank
+    o.rank = rank
+    o.world_size = world
+    ba = BundleAdjustment(pa, o)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).cuda()
+        dist.broadcast(uid, src=0)
+        ba.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()))
+    info = ba.info()
+    radius = 1e4
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    first = ba.sweep(radius)                       # also fixes the Jacobi scaling (iteration-0 semantics)
+    for _ in range(args.warmup):
+        ba.sweep_enqueue(radius)
+    ba.sweep(radius)
+    ba.profile_begin(args.steps)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ba.sweep_enqueue(radius)
+    prof = ba.profile_end()                        # synchronises the library's stream
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    last = ba.sweep(radius)
+    assert abs(last.cost - first.cost) <= 1e-9 * abs(first.cost), "sweep is not idempotent"
+
+    out = None
+    if rank == 0:
+        F_tot, P_tot = spec.n_frames * world, spec.n_points * world
+        n_loc = info.n_obs_local
+        n_red = 17 + 6 * F_tot
+        b_kernel = accumulate_kernel_bytes(n_loc, spec.n_points, spec.n_frames)
+        b_sweep = algorithmic_bytes(n_loc, spec.n_points, spec.n_frames, 17 + 6 * spec.n_frames)
+        t_kernel = prof.ms_accumulate * 1e-3
+        t_total = prof.ms_total * 1e-3
+        achieved = b_kernel / t_kernel / 1e9
+        out = {
+            "metric": "micro-image obs/sec through Jacobian+Schur at 1M obs",
+            "value": n_obs_total * args.steps / dt,
+            "unit": "obs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {F_tot} frames, {P_tot} points, {n_obs_total} micro-image observations, "
+                                   f"window {spec.window}, config {spec.config:#x} (2 radial + tangential, mlCenterAdj, Cauchy(0.5), refine poses+points)",
+                       "obs_per_gpu": n_loc, "n_reduced": n_red, "sharding": "by 3D point" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "kernel": "k_sweep (residual+Jacobian+block accumulation)",
+                         "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
+                         "traffic": load_traffic(args.workload),
+                         "algorithmic_bytes_per_launch": b_kernel, "kernel_ms": prof.ms_accumulate,
+                         "whole_sweep": {"algorithmic_bytes": b_sweep, "ms": prof.ms_total, "ms_schur": prof.ms_schur, "ms_tables": prof.ms_tables,
+                                         "achieved": b_sweep / t_total / 1e9, "frac": b_sweep / t_total / HBM_PEAK}},
+            "cost": last.cost,
+        }
+    ba.close()
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -178,6 +178,22 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s);
 /* one Jacobian+Schur sweep at trust-region radius `radius` on the CURRENT device-resident point */
 int lifcal_ba_sweep(lifcal_ba_handle* h, double radius, lifcal_ba_sweep_out* out);
 
+/* the same sweep without the host round trip: kernels are only enqueued on the handle's stream (read the
+ * result later with lifcal_ba_sweep, or synchronise the stream).  Used for back-to-back timing. */
+int lifcal_ba_sweep_enqueue(lifcal_ba_handle* h, double radius);
+
+/* HIP-event instrumentation of the sweep kernels, recorded on the stream the kernels run on.
+ * begin() reserves event pairs for up to max_sweeps sweeps; end() synchronises and averages. */
+typedef struct lifcal_ba_profile {
+  uint32_t n_sweeps;
+  double ms_tables;       /* camera constants + frame table + lens table                         */
+  double ms_accumulate;   /* k_sweep: residual + Jacobian + block accumulation (dominant kernel) */
+  double ms_schur;        /* k_schur: point-block inverse + Schur complement                      */
+  double ms_total;        /* first kernel of a sweep to the end of k_finalize                     */
+} lifcal_ba_profile;
+int lifcal_ba_profile_begin(lifcal_ba_handle* h, uint32_t max_sweeps);
+int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out);
+
 /* replaces reference :1026-1103 (evaluated on the device-resident parameters) */
 int lifcal_ba_reproj_stats(lifcal_ba_handle* h, double inlier_threshold, lifcal_ba_stats* out);
 

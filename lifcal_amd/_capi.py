@@ -68,6 +68,11 @@ class Info(C.Structure):
                 ("device_bytes", C.c_uint64), ("stream", C.c_void_p)]
 
 
+class Profile(C.Structure):
+    _fields_ = [("n_sweeps", C.c_uint32), ("ms_tables", C.c_double), ("ms_accumulate", C.c_double),
+                ("ms_schur", C.c_double), ("ms_total", C.c_double)]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [("n_groups", C.c_uint32), ("n_tiles", C.c_uint32), ("n_lenses", C.c_uint32), ("n_promoted", C.c_uint32),
                 ("n_reduced", C.c_uint32), ("max_group_obs", C.c_uint32), ("n_chunks", C.c_uint32),
@@ -82,6 +87,9 @@ PROTOTYPES = {
     "lifcal_ba_create": (C.c_int, [C.POINTER(Problem), C.POINTER(Options), C.POINTER(C.c_void_p)]),
     "lifcal_ba_solve": (C.c_int, [C.c_void_p, C.POINTER(Summary)]),
     "lifcal_ba_sweep": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(SweepOut)]),
+    "lifcal_ba_sweep_enqueue": (C.c_int, [C.c_void_p, C.c_double]),
+    "lifcal_ba_profile_begin": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "lifcal_ba_profile_end": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "lifcal_ba_reproj_stats": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(Stats)]),
     "lifcal_ba_upload_parameters": (C.c_int, [C.c_void_p]),
     "lifcal_ba_download_parameters": (C.c_int, [C.c_void_p]),

@@ -106,9 +106,19 @@ class BundleAdjustment:
         res.n_reduced = out.n_reduced; res.n_promoted = out.n_promoted
         return res
 
-    def sweep_raw(self, radius: float, out: capi.SweepOut) -> int:
-        """Thin call for timing loops (no Python allocation)."""
-        return self.lib.lifcal_ba_sweep(self._h, radius, C.byref(out))
+    def sweep_enqueue(self, radius: float = 1e4):
+        """Enqueue one sweep on the handle's stream without a host round trip (timing loops)."""
+        rc = self.lib.lifcal_ba_sweep_enqueue(self._h, float(radius))
+        if rc:
+            _check(self.lib, rc, "lifcal_ba_sweep_enqueue")
+
+    def profile_begin(self, max_sweeps: int):
+        _check(self.lib, self.lib.lifcal_ba_profile_begin(self._h, int(max_sweeps)), "lifcal_ba_profile_begin")
+
+    def profile_end(self) -> capi.Profile:
+        p = capi.Profile()
+        _check(self.lib, self.lib.lifcal_ba_profile_end(self._h, C.byref(p)), "lifcal_ba_profile_end")
+        return p
 
     # -- plumbing --------------------------------------------------------------------------------
     def upload_parameters(self):

@@ -89,6 +89,10 @@ struct lifcal_ba_handle {
   void* comm = nullptr;
   double last_cost = 0, last_gmax = 0;
   size_t chol_lds = 0;
+  // profiling: 5 events per sweep (start, after tables, after k_sweep, before k_schur, after k_schur, end)
+  std::vector<hipEvent_t> prof_events; uint32_t prof_cap = 0, prof_used = 0; bool prof_on = false;
+  hipEvent_t prof_ev(int which) { return prof_events[(size_t)prof_used * 6 + which]; }
+  bool prof_active() const { return prof_on && prof_used < prof_cap; }
 };
 
 namespace {
@@ -166,14 +170,17 @@ int launch_tables(lifcal_ba_handle* h, const double* cam, const double* views, C
 // Jacobian accumulation at the current point (independent of the trust-region radius)
 int launch_accumulate(lifcal_ba_handle* h) {
   Dev& d = h->d;
+  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));
   if (int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true)) return rc;
   HIP_TRY(hipMemsetAsync(h->red_block, 0, h->red_count * sizeof(double), h->stream));
   HIP_TRY(hipMemsetAsync(d.ptacc, 0, (size_t)d.P * 36 * sizeof(double), h->stream));
+  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(1), h->stream));
   if (d.n_tiles) {
 #define CALL_SWEEP(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep<NR, TAN, ADJ>), dim3(sweep_grid(h)), dim3(256), 0, h->stream, d)
     DISPATCH_CFG(h, CALL_SWEEP);
 #undef CALL_SWEEP
   }
+  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(2), h->stream));
   if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 0, (const double*)d.pts, d.scal + SCAL_COST);
   if (d.Q && d.use_points) hipLaunchKernelGGL(k_promote_diag, dim3((d.Q + 63) / 64), dim3(64), 0, h->stream, d);
   HIP_TRY(hipGetLastError());
@@ -199,12 +206,15 @@ int launch_accumulate(lifcal_ba_handle* h) {
 int launch_reduce(lifcal_ba_handle* h, double radius, bool restore) {
   Dev& d = h->d;
   if (restore) HIP_TRY(hipMemcpyAsync(h->red_block, h->red_save, h->red_count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(3), h->stream));
   if (d.use_points && d.n_owned && !getenv("LIFCAL_DEBUG_SKIP_SCHUR")) hipLaunchKernelGGL(k_schur, dim3((d.n_owned + 3) / 4), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
+  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(4), h->stream));
   if (int rc = do_allreduce(h, h->red_block, h->red_count)) return rc;
   HIP_TRY(hipMemsetAsync(d.step, 0, ST_N * sizeof(double), h->stream));
   hipLaunchKernelGGL(k_finalize, dim3((d.n_red + 255) / 256), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
+  if (h->prof_active()) { HIP_TRY(hipEventRecord(h->prof_ev(5), h->stream)); h->prof_used++; }
   return 0;
 }
 
@@ -447,6 +457,7 @@ void lifcal_ba_destroy(lifcal_ba_handle* h) {
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -484,6 +495,39 @@ int lifcal_ba_get_info(lifcal_ba_handle* h, lifcal_ba_info* out) {
   out->n_groups = h->plan.n_groups; out->n_tiles = h->plan.n_tiles; out->n_lenses = h->plan.n_lenses;
   out->n_reduced = h->plan.n_red_canon; out->n_promoted = h->plan.Q; out->n_chunks = h->plan.n_tiles; out->max_window_frames = h->d.bw + 1;
   out->device_bytes = h->bytes; out->stream = (void*)h->stream;
+  return 0;
+}
+
+int lifcal_ba_sweep_enqueue(lifcal_ba_handle* h, double radius) {
+  if (!h || !(radius > 0.0)) return LIFCAL_BA_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->opt.device));
+  if (int rc = launch_accumulate(h)) return rc;
+  return launch_reduce(h, radius, false);
+}
+
+int lifcal_ba_profile_begin(lifcal_ba_handle* h, uint32_t max_sweeps) {
+  if (!h) return LIFCAL_BA_ERR_INVALID_ARG;
+  HIP_TRY(hipSetDevice(h->opt.device));
+  while (h->prof_events.size() < (size_t)max_sweeps * 6) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->prof_events.push_back(e); }
+  h->prof_cap = max_sweeps; h->prof_used = 0; h->prof_on = true;
+  return 0;
+}
+
+int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out) {
+  if (!h || !out) return LIFCAL_BA_ERR_INVALID_ARG;
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  std::memset(out, 0, sizeof(*out));
+  const uint32_t n = h->prof_used;
+  for (uint32_t i = 0; i < n; ++i) {
+    float a = 0, b = 0, c = 0, t = 0;
+    hipEvent_t* e = &h->prof_events[(size_t)i * 6];
+    HIP_TRY(hipEventElapsedTime(&a, e[0], e[1])); HIP_TRY(hipEventElapsedTime(&b, e[1], e[2]));
+    HIP_TRY(hipEventElapsedTime(&c, e[3], e[4])); HIP_TRY(hipEventElapsedTime(&t, e[0], e[5]));
+    out->ms_tables += a; out->ms_accumulate += b; out->ms_schur += c; out->ms_total += t;
+  }
+  if (n) { out->ms_tables /= n; out->ms_accumulate /= n; out->ms_schur /= n; out->ms_total /= n; }
+  out->n_sweeps = n;
+  h->prof_on = false;
   return 0;
 }
 
