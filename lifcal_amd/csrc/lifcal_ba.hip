@@ -75,7 +75,9 @@ struct lifcal_ba_handle {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   std::vector<void*> allocs;
   uint64_t bytes = 0;
-  double* red_block = nullptr; double* red_save = nullptr; size_t red_count = 0;
+  double* red_block = nullptr; size_t red_count = 0;
+  size_t v2_lds_bytes = 0;
+  TileSet ts1{}, ts2{};   // v1 tiles, v2 tiles (flat view)
   double* partial = nullptr;     // 4 doubles + 1 cand cost (all-reduced)
   double* hdiag_tmp = nullptr;
   double* stats_buf = nullptr;   // 4 sums + 2 max bit patterns
@@ -167,25 +169,38 @@ int launch_tables(lifcal_ba_handle* h, const double* cam, const double* views, C
   return 0;
 }
 
-// Jacobian accumulation at the current point (independent of the trust-region radius)
-int launch_accumulate(lifcal_ba_handle* h) {
+// the kernels that turn observations into blocks.  mode 1 = Hessian diagonal only (Jacobi scaling, iteration 0)
+int launch_blocks(lifcal_ba_handle* h, double radius, int mode) {
   Dev& d = h->d;
-  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));
-  if (int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true)) return rc;
   HIP_TRY(hipMemsetAsync(h->red_block, 0, h->red_count * sizeof(double), h->stream));
   HIP_TRY(hipMemsetAsync(d.ptacc, 0, (size_t)d.P * 36 * sizeof(double), h->stream));
-  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(1), h->stream));
-  if (d.n_tiles) {
+  if (mode == 0 && h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(1), h->stream));
+  if (d.n_blocks) {   // regular points: LDS-window kernel, one workgroup per block
+#define CALL_SWEEP2(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep2<NR, TAN, ADJ>), dim3(d.n_blocks), dim3(256), h->v2_lds_bytes, h->stream, d, radius, mode)
+    DISPATCH_CFG(h, CALL_SWEEP2);
+#undef CALL_SWEEP2
+  }
+  if (d.n_tiles) {    // special points (constraints, promoted, oversized, camera-only / pose-only arities): global atomics
 #define CALL_SWEEP(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep<NR, TAN, ADJ>), dim3(sweep_grid(h)), dim3(256), 0, h->stream, d)
     DISPATCH_CFG(h, CALL_SWEEP);
 #undef CALL_SWEEP
   }
-  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(2), h->stream));
+  if (mode == 0 && h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(2), h->stream));
   if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 0, (const double*)d.pts, d.scal + SCAL_COST);
   if (d.Q && d.use_points) hipLaunchKernelGGL(k_promote_diag, dim3((d.Q + 63) / 64), dim3(64), 0, h->stream, d);
   HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// one Jacobian + Schur sweep at the current point and the given trust-region radius
+int launch_sweep(lifcal_ba_handle* h, double radius) {
+  Dev& d = h->d;
+  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));
+  if (int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true)) return rc;
   if (!h->sigma_valid) {
-    // ceres fixes the Jacobi scaling at iteration 0 from the column norms of the (loss-corrected) Jacobian
+    // ceres fixes the Jacobi scaling at iteration 0 from the column norms of the (loss-corrected) Jacobian:
+    // a diagonal-only pass, then 1 / (1 + sqrt(diag)) for every column
+    if (int rc = launch_blocks(h, radius, 1)) return rc;
     const double* hd = d.hdiag;
     if (h->opt.world_size > 1) {
       HIP_TRY(hipMemcpyAsync(h->hdiag_tmp, d.hdiag, d.n_red * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -198,16 +213,9 @@ int launch_accumulate(lifcal_ba_handle* h) {
     HIP_TRY(hipGetLastError());
     h->sigma_valid = true;
   }
-  HIP_TRY(hipMemcpyAsync(h->red_save, h->red_block, h->red_count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-  return 0;
-}
-
-// radius-dependent part: damp + eliminate the point blocks, reduce across ranks, finish the reduced system
-int launch_reduce(lifcal_ba_handle* h, double radius, bool restore) {
-  Dev& d = h->d;
-  if (restore) HIP_TRY(hipMemcpyAsync(h->red_block, h->red_save, h->red_count * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+  if (int rc = launch_blocks(h, radius, 0)) return rc;
   if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(3), h->stream));
-  if (d.use_points && d.n_owned && !getenv("LIFCAL_DEBUG_SKIP_SCHUR")) hipLaunchKernelGGL(k_schur, dim3((d.n_owned + 3) / 4), dim3(256), 0, h->stream, d, radius);
+  if (d.use_points && d.n_special) hipLaunchKernelGGL(k_schur, dim3((d.n_special + 3) / 4), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
   if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(4), h->stream));
   if (int rc = do_allreduce(h, h->red_block, h->red_count)) return rc;
@@ -251,8 +259,10 @@ int launch_candidate(lifcal_ba_handle* h) {
   HIP_TRY(hipGetLastError());
   if (int rc = launch_tables(h, d.cam_c, d.views_c, d.camc_c, d.ft_c, d.lt_c, false, true)) return rc;
   const double* pts_eval = d.use_points ? d.pts_c : d.pts;
-  if (d.n_tiles) {
-#define CALL_COST(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(sweep_grid(h)), dim3(256), 0, h->stream, d, (const CamConsts*)d.camc_c, (const double*)d.ft_c, (const double*)d.lt_c, pts_eval, h->partial + 4)
+  for (const TileSet* ts : {&h->ts1, &h->ts2}) {
+    if (!ts->n_tiles) continue;
+    const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 2048u));
+#define CALL_COST(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)d.camc_c, (const double*)d.ft_c, (const double*)d.lt_c, pts_eval, h->partial + 4)
     DISPATCH_CFG(h, CALL_COST);
 #undef CALL_COST
   }
@@ -360,7 +370,8 @@ int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size,
   if (int rc = build_plan(p, rank, world_size, &pl)) return rc;
   if (info) {
     info->n_groups = pl.n_groups; info->n_tiles = pl.n_tiles; info->n_lenses = pl.n_lenses; info->n_promoted = pl.Q;
-    info->n_reduced = pl.n_red_canon; info->max_group_obs = pl.max_group_obs; info->n_chunks = pl.n_tiles; info->max_window_frames = pl.bw + 1;
+    info->n_reduced = pl.n_red_canon; info->max_group_obs = pl.max_group_obs; info->n_chunks = pl.n_blocks; info->max_window_frames = pl.bw + 1;
+    info->n_tiles = pl.n_tiles + 4 * pl.n_passes;
   }
   if (obs_order) { for (uint32_t i = 0; i < p->n_obs; ++i) obs_order[i] = UINT32_MAX; for (size_t s = 0; s < pl.obs_order.size(); ++s) obs_order[s] = pl.obs_order[s]; }
   if (point_owner) for (uint32_t q = 0; q < p->n_points; ++q) point_owner[q] = (uint32_t)pl.owner[q];
@@ -376,7 +387,11 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   lifcal_ba_handle* h = new (std::nothrow) lifcal_ba_handle();
   if (!h) return LIFCAL_BA_ERR_NOMEM;
   h->opt = opt;
-  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan);
+  // tuning / A-B knobs (not part of the ABI): LIFCAL_DISABLE_V2=1 forces the global-atomic kernels,
+  // LIFCAL_V2_BLOCKS sets the number of workgroups the LDS-window sweep is cut into (default: one per CU)
+  const bool enable_v2 = getenv("LIFCAL_DISABLE_V2") == nullptr;
+  const uint32_t v2_blocks = getenv("LIFCAL_V2_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("LIFCAL_V2_BLOCKS"))) : 256u;
+  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks);
   if (rc) { delete h; return rc; }
   h->prob = *p;
   int ndev = 0;
@@ -417,13 +432,28 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   A(d.ft, (size_t)d.F * FRAME_STRIDE); A(d.ft_c, (size_t)d.F * FRAME_STRIDE);
   A(d.lt, (size_t)d.n_lenses * LENS_STRIDE); A(d.lt_c, (size_t)d.n_lenses * LENS_STRIDE);
   U(h->lens_xy, L.lens_xy);
-  { uint32_t* t; U(t, L.tile_row0); d.tile_row0 = t; U(t, L.slot_pt); d.slot_pt = t; U(t, L.slot_fr); d.slot_fr = t; U(t, L.slot_cnt); d.slot_cnt = t; U(t, L.ell_lens); d.ell_lens = t; }
+  { uint32_t* t; U(t, L.tile_row0); d.tile_row0 = t; U(t, L.slot_pt); d.slot_pt = t; U(t, L.slot_fr); d.slot_fr = t; U(t, L.slot_cnt); d.slot_cnt = t; U(t, L.ell_lens); d.ell_lens = t;
+    U(t, L.gid_fr); d.gid_fr = t; U(t, L.slot_gid); d.slot_gid = t; U(t, L.special_owned); d.special_owned = t;
+    U(t, L.blk_pass0); d.blk_pass0 = t; U(t, L.blk_flo); d.blk_flo = t; U(t, L.blk_nf); d.blk_nf = t;
+    U(t, L.pass_pt0); d.pass_pt0 = t; U(t, L.pass_np); d.pass_np = t; U(t, L.pass_gid0); d.pass_gid0 = t; U(t, L.pass_ng); d.pass_ng = t;
+    U(t, L.v2_points); d.v2_points = t; U(t, L.v2_slot); d.v2_slot = t; U(t, L.v2_tile_row0); d.v2_tile_row0 = t; U(t, L.v2_lens); d.v2_lens = t; }
+  { double* t; U(t, L.v2_u); d.v2_u = t; U(t, L.v2_v); d.v2_v = t; }
+  { uint32_t *a, *b, *c; U(a, L.v2f_pt); U(b, L.v2f_fr); U(c, L.v2f_cnt);
+    h->ts2 = TileSet{4 * L.n_passes, d.v2_tile_row0, a, b, c, d.v2_lens, d.v2_u, d.v2_v}; }
+  d.n_blocks = L.n_blocks; d.v2_nfmax = std::max(1u, L.max_block_nf); d.n_special = (uint32_t)L.special_owned.size();
+  h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax).total * sizeof(double);
+  if (d.n_blocks) {
+#define SET_LDS(NR, TAN, ADJ) do { if (hipFuncSetAttribute((const void*)k_sweep2<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); } while (0)
+    DISPATCH_CFG(h, SET_LDS);
+#undef SET_LDS
+  }
   { double* t; U(t, L.ell_u); d.ell_u = t; U(t, L.ell_v); d.ell_v = t; }
+  h->ts1 = TileSet{d.n_tiles, d.tile_row0, d.slot_pt, d.slot_fr, d.slot_cnt, d.ell_lens, d.ell_u, d.ell_v};
   { int32_t* t; U(t, L.promoted); d.promoted = t; }
   { uint32_t* t; U(t, L.promoted_ids); d.promoted_ids = t; U(t, L.pt_slot0); d.pt_slot0 = t; U(t, L.pt_nslots); d.pt_nslots = t; U(t, L.owned_points); d.owned = t; }
   { std::vector<uint8_t> live(L.frame_used); uint8_t* t; U(t, live); d.frame_live = t; }
   A(d.ptacc, (size_t)d.P * 36); A(d.Uinv, (size_t)d.P * 9); A(d.lamP, (size_t)d.P * 3); A(d.sigP, (size_t)d.P * 3);
-  A(d.Wv, (size_t)d.n_slots * 18);
+  A(d.Wv, (size_t)L.n_groups * 18);
   if (L.use_constraints) {
     uint32_t* t; U(t, L.c_i); d.c_i = t; U(t, L.c_j); d.c_j = t; U(t, L.my_constraints); d.my_cons = t;
     U(t, L.pt_cons0); d.pt_cons0 = t; U(t, L.pt_cons_list); d.pt_cons_list = t;
@@ -432,7 +462,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   }
   const size_t n_band = (size_t)d.F * (d.bw + 1) * 36, n_arrow = (size_t)(d.NA + 1) * d.ld;
   h->red_count = n_band + n_arrow + 3 * (size_t)d.n_red + SCAL_N;
-  A(h->red_block, h->red_count); A(h->red_save, h->red_count);
+  A(h->red_block, h->red_count);
   d.Sband = h->red_block; d.Sarrow = d.Sband + n_band; d.rhsacc = d.Sarrow + n_arrow; d.gB = d.rhsacc + d.n_red; d.hdiag = d.gB + d.n_red; d.scal = d.hdiag + d.n_red;
   A(d.sig_red, d.n_red); A(d.lam_red, d.n_red); A(d.delta_red, d.n_red); A(d.Linv, (size_t)d.F * 36 + 36);
   A(d.step, ST_N); A(h->partial, 8); A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->pts_gather, 3 * (size_t)d.P);
@@ -493,7 +523,8 @@ int lifcal_ba_get_info(lifcal_ba_handle* h, lifcal_ba_info* out) {
   if (!h || !out) return LIFCAL_BA_ERR_INVALID_ARG;
   out->n_obs_local = h->plan.n_obs_local; out->n_points_local = (uint32_t)h->plan.owned_points.size();
   out->n_groups = h->plan.n_groups; out->n_tiles = h->plan.n_tiles; out->n_lenses = h->plan.n_lenses;
-  out->n_reduced = h->plan.n_red_canon; out->n_promoted = h->plan.Q; out->n_chunks = h->plan.n_tiles; out->max_window_frames = h->d.bw + 1;
+  out->n_reduced = h->plan.n_red_canon; out->n_promoted = h->plan.Q; out->n_chunks = h->plan.n_blocks; out->max_window_frames = h->d.bw + 1;
+  out->n_tiles = h->plan.n_tiles + 4 * h->plan.n_passes;
   out->device_bytes = h->bytes; out->stream = (void*)h->stream;
   return 0;
 }
@@ -501,8 +532,7 @@ int lifcal_ba_get_info(lifcal_ba_handle* h, lifcal_ba_info* out) {
 int lifcal_ba_sweep_enqueue(lifcal_ba_handle* h, double radius) {
   if (!h || !(radius > 0.0)) return LIFCAL_BA_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->opt.device));
-  if (int rc = launch_accumulate(h)) return rc;
-  return launch_reduce(h, radius, false);
+  return launch_sweep(h, radius);
 }
 
 int lifcal_ba_profile_begin(lifcal_ba_handle* h, uint32_t max_sweeps) {
@@ -536,8 +566,7 @@ int lifcal_ba_sweep(lifcal_ba_handle* h, double radius, lifcal_ba_sweep_out* out
   Dev& d = h->d;
   HIP_TRY(hipSetDevice(h->opt.device));
   HIP_TRY(hipEventRecord(h->ev0, h->stream));
-  if (int rc = launch_accumulate(h)) return rc;
-  if (int rc = launch_reduce(h, radius, false)) return rc;
+  if (int rc = launch_sweep(h, radius)) return rc;
   HIP_TRY(hipEventRecord(h->ev1, h->stream));
   double cost, gmax, bad;
   if (int rc = read_sweep_scalars(h, &cost, &gmax, &bad)) return rc;
@@ -599,8 +628,7 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
   double radius = o.initial_radius, decrease_factor = 2.0;
   double x_cost, gmax, bad;
   double t0 = now_s();
-  if (int rc = launch_accumulate(h)) return rc;
-  if (int rc = launch_reduce(h, radius, false)) return rc;
+  if (int rc = launch_sweep(h, radius)) return rc;
   if (int rc = read_sweep_scalars(h, &x_cost, &gmax, &bad)) return rc;
   s->seconds_sweep += now_s() - t0;
   if (!std::isfinite(x_cost)) { g_last_error = "non-finite cost at the initial point"; return LIFCAL_BA_ERR_NUMERIC; }
@@ -615,9 +643,9 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
     if (step_successful && gmax <= o.gradient_tolerance) { s->termination = LIFCAL_BA_TERM_GRADIENT_TOLERANCE; break; }
     if (radius < o.min_radius) { s->termination = LIFCAL_BA_TERM_MIN_RADIUS; break; }
     ++iteration;
-    if (!system_ready) {  // same Jacobian, new radius: rebuild the damped reduced system from the snapshot
+    if (!system_ready) {  // same point, new radius: the fused sweep is cheap enough to simply run again
       t0 = now_s();
-      if (int rc = launch_reduce(h, radius, true)) return rc;
+      if (int rc = launch_sweep(h, radius)) return rc;
       s->seconds_sweep += now_s() - t0;
     }
     system_ready = false;
@@ -650,8 +678,7 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
       radius = radius / std::max(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3));
       radius = std::min(o.max_radius, radius);
       decrease_factor = 2.0;
-      if (int rc = launch_accumulate(h)) return rc;
-      if (int rc = launch_reduce(h, radius, false)) return rc;
+      if (int rc = launch_sweep(h, radius)) return rc;
       if (int rc = read_sweep_scalars(h, &x_cost, &gmax, &bad)) return rc;
       s->seconds_sweep += now_s() - t0;
       system_ready = true; step_successful = true; ++s->successful_steps;
@@ -673,8 +700,10 @@ int lifcal_ba_reproj_stats(lifcal_ba_handle* h, double thr, lifcal_ba_stats* out
   // reference :1028-1039: parameters are used as stored (no sign folding), scale goes through a float cast
   if (int rc = launch_tables(h, d.cam, d.views, h->camc_stats, d.ft_c, d.lt_c, false, false)) return rc;
   HIP_TRY(hipMemsetAsync(h->stats_buf, 0, 8 * sizeof(double), h->stream));
-  if (d.n_tiles) {
-#define CALL_STATS(NR, TAN, ADJ) hipLaunchKernelGGL((k_stats<NR, TAN, ADJ>), dim3(sweep_grid(h)), dim3(256), 0, h->stream, d, (const CamConsts*)h->camc_stats, (const double*)d.ft_c, (const double*)d.lt_c, (const double*)d.pts, thr * thr, h->stats_buf, (unsigned long long*)(h->stats_buf + 4))
+  for (const TileSet* ts : {&h->ts1, &h->ts2}) {
+    if (!ts->n_tiles) continue;
+    const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 2048u));
+#define CALL_STATS(NR, TAN, ADJ) hipLaunchKernelGGL((k_stats<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)h->camc_stats, (const double*)d.ft_c, (const double*)d.lt_c, (const double*)d.pts, thr * thr, h->stats_buf, (unsigned long long*)(h->stats_buf + 4))
     DISPATCH_CFG(h, CALL_STATS);
 #undef CALL_STATS
   }

@@ -58,6 +58,25 @@ struct Plan {
   // per point: its slots are contiguous [pt_slot0[p], pt_slot0[p]+pt_nslots[p])
   std::vector<uint32_t> pt_slot0, pt_nslots;
   std::vector<uint32_t> owned_points;  // points this rank owns (observed or constrained), in point_order
+  // "group id" (gid): running index of (point, frame) groups in point-major order over BOTH paths; the W_pose
+  // staging in HBM (18 doubles per group) is indexed by gid, a point's groups are contiguous.
+  std::vector<uint32_t> gid_fr;        // frame of each group
+  std::vector<uint32_t> slot_gid;      // v1 path: gid of each slot
+  // ---- v2 (LDS-window) path: regular points only -------------------------------------------------
+  // block  = one workgroup: contiguous range of points whose frames fit a window of <= NF_MAX frames
+  // pass   = <= 256 groups / <= 64 points of a block (4 tiles, group g -> wave g%4, lane g/4)
+  static constexpr uint32_t NF_MAX = 20, NP_MAX = 64, PASS_GROUPS = 256;
+  uint32_t n_blocks = 0, n_passes = 0, max_block_nf = 0;
+  std::vector<uint32_t> blk_pass0;     // n_blocks+1
+  std::vector<uint32_t> blk_flo, blk_nf;
+  std::vector<uint32_t> pass_pt0, pass_np, pass_gid0, pass_ng;   // per pass: first entry in v2_points, #points, first gid, #groups
+  std::vector<uint32_t> v2_points;     // point ids in processing order
+  std::vector<uint32_t> v2_slot;       // per (pass*256 + wave*64 + lane): cnt | lf<<8 | lp<<16 ; 0 = idle
+  std::vector<uint32_t> v2f_pt, v2f_fr, v2f_cnt;   // the same slots, flat (value-only kernels: cost, statistics)
+  std::vector<uint32_t> v2_tile_row0;  // 4*n_passes+1
+  std::vector<double> v2_u, v2_v; std::vector<uint32_t> v2_lens, v2_src;
+  std::vector<uint32_t> special_owned; // owned points handled by the v1 kernels (promoted / constrained / oversized)
+  uint32_t n_obs_v2 = 0;
   // lenses
   std::vector<double> lens_xy;         // 2 per lens
   uint32_t n_lenses = 0;
@@ -84,7 +103,7 @@ inline int plan_validate(const lifcal_ba_problem* p) {
   return 0;
 }
 
-inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl) {
+inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl, bool enable_v2 = true, uint32_t target_blocks = 256) {
   if (int rc = plan_validate(p)) return rc;
   if (world < 1 || rank < 0 || rank >= world) return LIFCAL_BA_ERR_INVALID_ARG;
   Plan& L = *pl;
@@ -175,7 +194,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl)
   }
   L.n_lenses = (uint32_t)(L.lens_xy.size() / 2);
 
-  // --- groups (runs of equal (point, frame)) -> slots -> tiles ---
+  // --- groups (runs of equal (point, frame)), gid numbering ---
   struct Group { uint32_t pt, fr, s0, n; };
   std::vector<Group> groups;
   for (uint32_t s = 0; s < L.n_obs_local;) {
@@ -186,32 +205,134 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl)
     s = e;
   }
   L.n_groups = (uint32_t)groups.size();
-  L.n_tiles = (L.n_groups + 63) / 64;
-  L.n_slots = L.n_tiles * 64;
-  L.slot_pt.assign(L.n_slots, 0); L.slot_fr.assign(L.n_slots, 0); L.slot_cnt.assign(L.n_slots, 0);
-  L.tile_row0.assign(L.n_tiles + 1, 0);
-  L.max_group_obs = 0;
-  for (uint32_t t = 0; t < L.n_tiles; ++t) {
-    uint32_t kmax = 0;
-    for (uint32_t l = 0; l < 64; ++l) { const uint32_t g = t * 64 + l; if (g < L.n_groups) kmax = std::max(kmax, groups[g].n); }
-    L.tile_row0[t + 1] = L.tile_row0[t] + kmax;
-    L.max_group_obs = std::max(L.max_group_obs, kmax);
-  }
-  const size_t rows = L.tile_row0[L.n_tiles];
-  L.ell_u.assign(rows * 64, 0.0); L.ell_v.assign(rows * 64, 0.0);
-  L.ell_lens.assign(rows * 64, 0); L.ell_src.assign(rows * 64, UINT32_MAX);
+  L.gid_fr.resize(L.n_groups);
   L.pt_slot0.assign(L.P, 0); L.pt_nslots.assign(L.P, 0);
   for (uint32_t g = 0; g < L.n_groups; ++g) {
-    const Group& G = groups[g];
-    const uint32_t t = g / 64, l = g % 64;
-    L.slot_pt[g] = G.pt; L.slot_fr[g] = G.fr; L.slot_cnt[g] = G.n;
-    if (L.pt_nslots[G.pt] == 0) L.pt_slot0[G.pt] = g;
-    L.pt_nslots[G.pt]++;
-    for (uint32_t k = 0; k < G.n; ++k) {
-      const size_t at = ((size_t)L.tile_row0[t] + k) * 64 + l;
-      const uint32_t i = L.obs_order[G.s0 + k];
-      L.ell_u[at] = p->u[i]; L.ell_v[at] = p->v[i]; L.ell_lens[at] = obs_lens[G.s0 + k]; L.ell_src[at] = i;
+    L.gid_fr[g] = groups[g].fr;
+    if (L.pt_nslots[groups[g].pt] == 0) L.pt_slot0[groups[g].pt] = g;
+    L.pt_nslots[groups[g].pt]++;
+  }
+  L.max_group_obs = 0;
+  for (const Group& G : groups) L.max_group_obs = std::max(L.max_group_obs, G.n);
+
+  // --- classify points: regular (v2) or special (v1 fallback) ---
+  std::vector<uint8_t> special(L.P, 0);
+  if (L.use_constraints) for (uint32_t c = 0; c < L.M; ++c) { special[L.c_i[c]] = 1; special[L.c_j[c]] = 1; }
+  for (uint32_t q = 0; q < L.P; ++q) {
+    if (!cnt[q]) continue;
+    if (!enable_v2 || !L.use_points) special[q] = 1;                    // camera-only / pose-only arities: v1 kernels
+    if (last[q] - first[q] + 1 > Plan::NF_MAX || L.pt_nslots[q] > Plan::PASS_GROUPS) special[q] = 1;
+  }
+
+  // --- v1 tiles from the special points' groups ---
+  std::vector<uint32_t> g1;
+  for (uint32_t g = 0; g < L.n_groups; ++g) if (special[groups[g].pt]) g1.push_back(g);
+  L.n_tiles = ((uint32_t)g1.size() + 63) / 64;
+  L.n_slots = L.n_tiles * 64;
+  L.slot_pt.assign(L.n_slots, 0); L.slot_fr.assign(L.n_slots, 0); L.slot_cnt.assign(L.n_slots, 0); L.slot_gid.assign(L.n_slots, 0);
+  L.tile_row0.assign(L.n_tiles + 1, 0);
+  for (uint32_t t = 0; t < L.n_tiles; ++t) {
+    uint32_t kmax = 0;
+    for (uint32_t l = 0; l < 64; ++l) { const uint32_t k = t * 64 + l; if (k < g1.size()) kmax = std::max(kmax, groups[g1[k]].n); }
+    L.tile_row0[t + 1] = L.tile_row0[t] + kmax;
+  }
+  {
+    const size_t rows = L.tile_row0[L.n_tiles];
+    L.ell_u.assign(rows * 64, 0.0); L.ell_v.assign(rows * 64, 0.0);
+    L.ell_lens.assign(rows * 64, 0); L.ell_src.assign(rows * 64, UINT32_MAX);
+    for (uint32_t k = 0; k < g1.size(); ++k) {
+      const Group& G = groups[g1[k]];
+      const uint32_t t = k / 64, l = k % 64;
+      L.slot_pt[k] = G.pt; L.slot_fr[k] = G.fr; L.slot_cnt[k] = G.n; L.slot_gid[k] = g1[k];
+      for (uint32_t j = 0; j < G.n; ++j) {
+        const size_t at = ((size_t)L.tile_row0[t] + j) * 64 + l;
+        const uint32_t i = L.obs_order[G.s0 + j];
+        L.ell_u[at] = p->u[i]; L.ell_v[at] = p->v[i]; L.ell_lens[at] = obs_lens[G.s0 + j]; L.ell_src[at] = i;
+      }
     }
+  }
+
+  // --- v2 blocks / passes from the regular points (already in point order) ---
+  L.v2_points.clear(); L.blk_pass0.assign(1, 0); L.blk_flo.clear(); L.blk_nf.clear();
+  L.pass_pt0.clear(); L.pass_np.clear(); L.pass_gid0.clear(); L.pass_ng.clear();
+  L.n_obs_v2 = 0;
+  {
+    std::vector<uint32_t> reg;
+    uint64_t reg_obs = 0;
+    for (uint32_t q : L.owned_points) if (!special[q] && L.pt_nslots[q] > 0) { reg.push_back(q); reg_obs += cnt[q]; }
+    L.n_obs_v2 = (uint32_t)reg_obs;
+    // blocks: contiguous ranges with ~reg_obs/target observations each, window <= NF_MAX
+    const uint64_t per_block = std::max<uint64_t>(1, (reg_obs + target_blocks - 1) / std::max(1u, target_blocks));
+    size_t i = 0;
+    while (i < reg.size()) {
+      uint32_t flo = UINT32_MAX, fhi = 0; uint64_t obs = 0; size_t j = i;
+      while (j < reg.size()) {
+        const uint32_t q = reg[j];
+        const uint32_t nlo = std::min(flo, first[q]), nhi = std::max(fhi, last[q]);
+        if (j > i && (nhi - nlo + 1 > Plan::NF_MAX || obs >= per_block)) break;
+        flo = nlo; fhi = nhi; obs += cnt[q]; ++j;
+      }
+      L.blk_flo.push_back(flo); L.blk_nf.push_back(fhi - flo + 1);
+      L.max_block_nf = std::max(L.max_block_nf, fhi - flo + 1);
+      // passes inside the block
+      size_t a = i;
+      while (a < j) {
+        uint32_t ng = 0, np = 0; size_t e = a;
+        // a pass covers one contiguous run of gids (a special point's groups in between end the pass)
+        while (e < j && np < Plan::NP_MAX && ng + L.pt_nslots[reg[e]] <= Plan::PASS_GROUPS &&
+               (e == a || L.pt_slot0[reg[e]] == L.pt_slot0[reg[e - 1]] + L.pt_nslots[reg[e - 1]])) { ng += L.pt_nslots[reg[e]]; ++np; ++e; }
+        L.pass_pt0.push_back((uint32_t)L.v2_points.size()); L.pass_np.push_back(np);
+        L.pass_gid0.push_back(L.pt_slot0[reg[a]]); L.pass_ng.push_back(ng);
+        for (size_t k = a; k < e; ++k) L.v2_points.push_back(reg[k]);
+        a = e;
+      }
+      L.blk_pass0.push_back((uint32_t)L.pass_pt0.size());
+      i = j;
+    }
+  }
+  L.n_blocks = (uint32_t)L.blk_flo.size(); L.n_passes = (uint32_t)L.pass_pt0.size();
+  L.v2_slot.assign((size_t)L.n_passes * 256, 0);
+  L.v2f_pt.assign((size_t)L.n_passes * 256, 0); L.v2f_fr.assign((size_t)L.n_passes * 256, 0); L.v2f_cnt.assign((size_t)L.n_passes * 256, 0);
+  L.v2_tile_row0.assign((size_t)L.n_passes * 4 + 1, 0);
+  {
+    // a pass's groups are contiguous gids (regular points between two specials may be split by a special
+    // point's groups, so walk the pass's points explicitly)
+    std::vector<std::vector<uint32_t>> pass_groups(L.n_passes);
+    for (uint32_t b = 0; b < L.n_blocks; ++b)
+      for (uint32_t ps = L.blk_pass0[b]; ps < L.blk_pass0[b + 1]; ++ps)
+        for (uint32_t k = 0; k < L.pass_np[ps]; ++k) {
+          const uint32_t q = L.v2_points[L.pass_pt0[ps] + k];
+          for (uint32_t g = L.pt_slot0[q]; g < L.pt_slot0[q] + L.pt_nslots[q]; ++g) pass_groups[ps].push_back(g);
+        }
+    for (uint32_t ps = 0; ps < L.n_passes; ++ps)
+      for (uint32_t w = 0; w < 4; ++w) {
+        uint32_t kmax = 0;
+        for (uint32_t g = w; g < pass_groups[ps].size(); g += 4) kmax = std::max(kmax, groups[pass_groups[ps][g]].n);
+        L.v2_tile_row0[(size_t)ps * 4 + w + 1] = L.v2_tile_row0[(size_t)ps * 4 + w] + kmax;
+      }
+    const size_t rows = L.v2_tile_row0[(size_t)L.n_passes * 4];
+    L.v2_u.assign(rows * 64, 0.0); L.v2_v.assign(rows * 64, 0.0); L.v2_lens.assign(rows * 64, 0); L.v2_src.assign(rows * 64, UINT32_MAX);
+    for (uint32_t b = 0; b < L.n_blocks; ++b)
+      for (uint32_t ps = L.blk_pass0[b]; ps < L.blk_pass0[b + 1]; ++ps) {
+        // local point index of each group
+        uint32_t lp = 0, left = 0;
+        for (uint32_t g = 0; g < pass_groups[ps].size(); ++g) {
+          const Group& G = groups[pass_groups[ps][g]];
+          if (g == 0) { lp = 0; left = L.pt_nslots[G.pt]; }
+          else if (left == 0) { ++lp; left = L.pt_nslots[G.pt]; }
+          --left;
+          const uint32_t w = g % 4, l = g / 4;
+          L.v2_slot[(size_t)ps * 256 + w * 64 + l] = G.n | ((G.fr - L.blk_flo[b]) << 8) | (lp << 16);
+          L.v2f_pt[(size_t)ps * 256 + w * 64 + l] = G.pt; L.v2f_fr[(size_t)ps * 256 + w * 64 + l] = G.fr; L.v2f_cnt[(size_t)ps * 256 + w * 64 + l] = G.n;
+          for (uint32_t j = 0; j < G.n; ++j) {
+            const size_t at = ((size_t)L.v2_tile_row0[(size_t)ps * 4 + w] + j) * 64 + l;
+            const uint32_t i = L.obs_order[G.s0 + j];
+            L.v2_u[at] = p->u[i]; L.v2_v[at] = p->v[i]; L.v2_lens[at] = obs_lens[G.s0 + j]; L.v2_src[at] = i;
+          }
+        }
+        // the pass's gids must be one contiguous run for the W staging (true unless a special point sits inside)
+        L.pass_gid0[ps] = pass_groups[ps].empty() ? 0 : pass_groups[ps][0];
+      }
   }
 
   // --- constraints owned by this rank; CSR of partner columns per eliminated point ---
@@ -227,6 +348,8 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl)
     // a point that is only constrained (never observed) still needs an owner
     for (uint32_t c = 0; c < L.M; ++c) if (L.owner[L.c_i[c]] < 0) { L.owner[L.c_i[c]] = 0; if (rank == 0) L.owned_points.push_back(L.c_i[c]); }
   }
+  L.special_owned.clear();
+  for (uint32_t q : L.owned_points) if (special[q] || L.pt_nslots[q] == 0) L.special_owned.push_back(q);
   return 0;
 }
 
