@@ -61,7 +61,7 @@ struct Dev {
   const uint32_t *gid_fr, *slot_gid;              // frame of each group id; v1 path: group id of each slot
   // v2 (LDS-window) path
   uint32_t n_blocks, v2_nfmax, n_special;
-  const uint32_t *blk_pass0, *blk_flo, *blk_nf, *pass_pt0, *pass_np, *pass_gid0, *pass_ng, *v2_points, *v2_slot, *v2_tile_row0, *v2_lens;
+  const uint32_t *blk_pass0, *blk_flo, *blk_nf, *pass_pt0, *pass_np, *pass_gid0, *pass_ng, *v2_points, *v2_ptinfo, *v2_slot, *v2_tile_row0, *v2_lens;
   const double *v2_u, *v2_v;
   const uint32_t* special_owned;
   // constraints
@@ -71,6 +71,7 @@ struct Dev {
   double *Sband, *Sarrow, *rhsacc, *gB, *hdiag, *scal;
   double *sig_red, *lam_red, *delta_red, *Linv;  // n_red, n_red, n_red, 36F
   double* step;                  // ST_N scalars
+  unsigned long long* dbg;       // diagnostic build only (LIFCAL_STAMPS): per-block phase cycle counts
 };
 
 LIFCAL_DEV double* s_addr(const Dev& d, uint32_t row, uint32_t col) {  // row >= col, internal ordering
@@ -309,414 +310,9 @@ __global__ __launch_bounds__(256) void k_sweep(Dev d) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// sweep, version 2: one WORKGROUP owns a contiguous range of points ("block") whose frames fit a window of
-// nf <= 20 frames.  Everything the block accumulates lives in LDS until one flush at the end:
-//   Spp  pose x pose blocks of the window (lower block triangle, 36 doubles each)
-//   Scp  camera x pose, Scc camera x camera, vec = gradient / diagonal / rhs of the window + camera
-//   slab U(6) g(3) Wc(27) per point of the current pass, wv = W_pose per group of the pass ([e][group])
-// A pass = <= 256 groups / <= 64 points (group g -> wave g%4, lane g/4, so lanes of one wave instruction collide on
-// few LDS addresses).  Per pass: (1) lanes walk their observations and add their rotated blocks with LDS atomics,
-// (2) one thread per point damps and factors U = L L^T, (3) W is stored to HBM for the back-substitution and
-// replaced in LDS by Z = L^-1 W, (4) Spp -= Z^T Z etc. with exclusive ownership of destination sub-blocks.
-// mode 1 ("diagonal only", iteration 0): just the Hessian diagonal for the Jacobi scaling.
-// ---------------------------------------------------------------------------------------------
-struct V2Lds {
-  uint32_t nfm, off_cp, off_cc, off_vec, off_slab, off_wv, off_fmap, off_misc, total;
-  __host__ __device__ explicit V2Lds(uint32_t nfmax) {
-    nfm = nfmax;
-    const uint32_t npp = nfm * (nfm + 1) / 2;
-    off_cp = npp * 36; off_cc = off_cp + NCMAX * 6 * nfm; off_vec = off_cc + 48;
-    off_slab = off_vec + 3 * (6 * nfm + NCMAX + 3);
-    off_slab = (off_slab + 1) & ~1u;
-    off_wv = off_slab + 64 * 36; off_fmap = off_wv + 18 * 256; off_misc = off_fmap + (64 * nfm + 3) / 4; total = off_misc + 8;
-  }
-};
-
-template <int NR, bool TAN, bool ADJ>
-__global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) {
-  constexpr int NC = 5 + NR + (TAN ? 2 : 0);
-  constexpr int NCC = NC * (NC + 1) / 2;
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const V2Lds lay(d.v2_nfmax);
-  const uint32_t NFm = lay.nfm, vlen = 6 * NFm + NCMAX + 3;
-  double* Spp = sm; double* Scp = sm + lay.off_cp; double* Scc = sm + lay.off_cc;
-  double* vgB = sm + lay.off_vec; double* vhd = vgB + vlen; double* vrhs = vhd + vlen;
-  double* slab = sm + lay.off_slab; double* wv = sm + lay.off_wv;
-  unsigned short* fmap = (unsigned short*)(sm + lay.off_fmap);
-  double* misc = sm + lay.off_misc;  // [0] cost, [1] bad-U count, [2] max |g_p| (as bits)
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-  const uint32_t b = blockIdx.x;
-  const uint32_t flo = d.blk_flo[b], nf = d.blk_nf[b];
-  const CamConsts c = *d.camc;
-  for (uint32_t i = tid; i < lay.off_slab; i += 256) sm[i] = 0.0;
-  if (tid < 8) misc[tid] = 0.0;
-  double cc[NCC], gc[NC], cost = 0.0;
-#pragma unroll
-  for (int i = 0; i < NCC; ++i) cc[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < NC; ++i) gc[i] = 0.0;
-
-  for (uint32_t ps = d.blk_pass0[b]; ps < d.blk_pass0[b + 1]; ++ps) {
-    const uint32_t np = d.pass_np[ps], ng = d.pass_ng[ps], pt0 = d.pass_pt0[ps], gid0 = d.pass_gid0[ps];
-    for (uint32_t i = tid; i < 64 * 36; i += 256) slab[i] = 0.0;
-    for (uint32_t i = tid; i < 64 * NFm; i += 256) fmap[i] = 0xFFFFu;
-    __syncthreads();
-    // ---------------- phase 1: observations -> LDS blocks ----------------
-    {
-      const uint32_t si = d.v2_slot[(size_t)ps * 256 + w * 64 + lane];
-      const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = si >> 16;
-      const uint32_t g = lane * 4 + w;
-      const uint32_t tile = ps * 4 + w;
-      const uint32_t row0 = d.v2_tile_row0[tile], kmax = d.v2_tile_row0[tile + 1] - row0;
-      const uint32_t pt = d.v2_points[pt0 + (cnt ? lp : 0)], fr = flo + lf;
-      double R[9], Y[3], c0, s0;
-      GroupConsts gcn;
-      {
-        const double* ft = d.ft + (size_t)fr * FRAME_STRIDE;
-        const double* P = d.pts + 3 * (size_t)pt;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = ft[k];
-        const double P0 = P[0], P1 = P[1], P2 = P[2];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) Y[k] = R[3 * k] * P0 + R[3 * k + 1] * P1 + R[3 * k + 2] * P2;
-        c0 = ft[12]; s0 = ft[13];
-        group_prepare(c, Y[0] + ft[9], Y[1] + ft[10], Y[2] + ft[11], gcn);
-      }
-      double A[6] = {0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0}, C[3][NC];
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < NC; ++j) C[i][j] = 0.0;
-      for (uint32_t k = 0; k < kmax; ++k) {
-        if (k < cnt) {
-          const size_t at = ((size_t)row0 + k) * 64 + lane;
-          const double u = d.v2_u[at], v = d.v2_v[at];
-          const double* L = d.lt + (size_t)d.v2_lens[at] * LENS_STRIDE;
-          double r[2], Jq[2][3], Jc[2][NC];
-          obs_eval<NR, TAN, ADJ>(c, gcn, L, u, v, r, Jq, Jc);
-          const double sq = r[0] * r[0] + r[1] * r[1];
-          if (d.robust) {
-            const double sum = 1.0 + sq * c.loss_c;
-            const double inv = 1.0 / sum;
-            cost += 0.5 * c.loss_b * log(sum);
-            const double sc = sqrt(fmax(inv, 2.2250738585072014e-308));
-            r[0] *= sc; r[1] *= sc;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-#pragma unroll
-              for (int j = 0; j < 3; ++j) Jq[a][j] *= sc;
-#pragma unroll
-              for (int j = 0; j < NC; ++j) Jc[a][j] *= sc;
-            }
-          } else {
-            cost += 0.5 * sq;
-          }
-#pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            A[0] += Jq[a][0] * Jq[a][0]; A[1] += Jq[a][0] * Jq[a][1]; A[2] += Jq[a][0] * Jq[a][2];
-            A[3] += Jq[a][1] * Jq[a][1]; A[4] += Jq[a][1] * Jq[a][2]; A[5] += Jq[a][2] * Jq[a][2];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) bv[i] += Jq[a][i] * r[a];
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-              for (int j = 0; j < NC; ++j) C[i][j] += Jq[a][i] * Jc[a][j];
-            int t = 0;
-#pragma unroll
-            for (int i = 0; i < NC; ++i) {
-              gc[i] += Jc[a][i] * r[a];
-#pragma unroll
-              for (int j = 0; j <= i; ++j) cc[t++] += Jc[a][i] * Jc[a][j];
-            }
-          }
-        }
-      }
-      if (cnt > 0) {
-        const double Am[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
-        const double n0 = R[2], n1 = R[5], n2 = R[8];
-        const double Gr[3][3] = {{0.0, c0 * Y[2] - s0 * Y[1], n1 * Y[2] - n2 * Y[1]},
-                                 {-Y[2], s0 * Y[0], n2 * Y[0] - n0 * Y[2]},
-                                 {Y[1], -c0 * Y[0], n0 * Y[1] - n1 * Y[0]}};
-        double AG[3][3], GAG[3][3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) AG[i][j] = Am[i][0] * Gr[0][j] + Am[i][1] * Gr[1][j] + Am[i][2] * Gr[2][j];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) GAG[i][j] = Gr[0][i] * AG[0][j] + Gr[1][i] * AG[1][j] + Gr[2][i] * AG[2][j];
-        fmap[lp * NFm + lf] = (unsigned short)g;
-        double* Sd = Spp + (size_t)(lf * (lf + 1) / 2 + lf) * 36;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-          for (int bb = 0; bb <= a; ++bb) {
-            double v;
-            if (a < 3) v = GAG[a][bb]; else if (bb < 3) v = AG[a - 3][bb]; else v = Am[a - 3][bb - 3];
-            atomicAdd(Sd + a * 6 + bb, v);
-            if (a == bb) atomicAdd(vhd + 6 * lf + a, v);
-          }
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          atomicAdd(vgB + 6 * lf + a, Gr[0][a] * bv[0] + Gr[1][a] * bv[1] + Gr[2][a] * bv[2]);
-          atomicAdd(vgB + 6 * lf + 3 + a, bv[a]);
-        }
-        if (mode == 0) {
-#pragma unroll
-          for (int j = 0; j < NC; ++j) {
-            double* row = Scp + (size_t)j * 6 * NFm + 6 * lf;
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci) atomicAdd(row + ci, C[0][j] * Gr[0][ci] + C[1][j] * Gr[1][ci] + C[2][j] * Gr[2][ci]);
-#pragma unroll
-            for (int ci = 0; ci < 3; ++ci) atomicAdd(row + 3 + ci, C[ci][j]);
-          }
-        }
-        double AR[3][3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) AR[i][j] = Am[i][0] * R[j] + Am[i][1] * R[3 + j] + Am[i][2] * R[6 + j];
-        double* acc = slab + lp * 36;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-          for (int j = 0; j <= i; ++j) {
-            const double u_ij = R[i] * AR[0][j] + R[3 + i] * AR[1][j] + R[6 + i] * AR[2][j];
-            const int pos = (i == 0) ? 0 : (i == 1 ? (j == 0 ? 1 : 3) : (j == 0 ? 2 : (j == 1 ? 4 : 5)));
-            atomicAdd(acc + pos, u_ij);
-          }
-        }
-        if (mode == 0) {
-#pragma unroll
-          for (int i = 0; i < 3; ++i) {
-            atomicAdd(acc + 6 + i, R[i] * bv[0] + R[3 + i] * bv[1] + R[6 + i] * bv[2]);
-#pragma unroll
-            for (int j = 0; j < NC; ++j) atomicAdd(acc + 9 + i * NCMAX + j, R[i] * C[0][j] + R[3 + i] * C[1][j] + R[6 + i] * C[2][j]);
-#pragma unroll
-            for (int j = 0; j < 3; ++j) wv[(i * 6 + j) * 256 + g] = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) wv[(i * 6 + 3 + j) * 256 + g] = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j];
-          }
-        }
-      }
-    }
-    __syncthreads();
-    // ---------------- phase 2: one thread per point: damp, factor U = L L^T ----------------
-    if (tid < np) {
-      const uint32_t p = d.v2_points[pt0 + tid];
-      double* acc = slab + tid * 36;
-      double U0 = acc[0], U1 = acc[1], U2 = acc[2], U3 = acc[3], U4 = acc[4], U5 = acc[5];
-      if (mode == 1) {
-        double* ga = d.ptacc + (size_t)p * 36;
-        ga[0] = U0; ga[3] = U3; ga[5] = U5;
-      } else {
-        const double g0 = acc[6], g1 = acc[7], g2 = acc[8];
-        double lam[3];
-        {
-          const double h[3] = {U0, U3, U5};
-#pragma unroll
-          for (int k = 0; k < 3; ++k) { const double sg = d.sigP[3 * (size_t)p + k]; lam[k] = fmin(fmax(h[k] * sg * sg, d.lm_min), d.lm_max) / (radius * sg * sg); }
-        }
-        U0 += lam[0]; U3 += lam[1]; U5 += lam[2];
-        bool ok = true;
-        double l00 = U0; ok = ok && (l00 > 0.0); l00 = sqrt(l00);
-        const double l10 = U1 / l00, l20 = U2 / l00;
-        double l11 = U3 - l10 * l10; ok = ok && (l11 > 0.0); l11 = sqrt(l11);
-        const double l21 = (U4 - l20 * l10) / l11;
-        double l22 = U5 - l20 * l20 - l21 * l21; ok = ok && (l22 > 0.0); l22 = sqrt(l22);
-        double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
-        double m10 = -l10 * i00 * i11, m21 = -l21 * i11 * i22, m20 = -(l20 * i00 + l21 * m10) * i22;
-        if (!ok) { i00 = i11 = i22 = m10 = m21 = m20 = 0.0; atomicAdd(misc + 1, 1.0); }
-        double* gu = d.Uinv + 9 * (size_t)p;
-        const double v00 = i00 * i00 + m10 * m10 + m20 * m20, v01 = m10 * i11 + m20 * m21, v02 = m20 * i22;
-        const double v11 = i11 * i11 + m21 * m21, v12 = m21 * i22, v22 = i22 * i22;
-        gu[0] = v00; gu[1] = v01; gu[2] = v02; gu[3] = v01; gu[4] = v11; gu[5] = v12; gu[6] = v02; gu[7] = v12; gu[8] = v22;
-        double* gl = d.lamP + 3 * (size_t)p; gl[0] = lam[0]; gl[1] = lam[1]; gl[2] = lam[2];
-        double* ga = d.ptacc + (size_t)p * 36;
-        ga[6] = g0; ga[7] = g1; ga[8] = g2;
-        const double gm = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
-        atomicMax((unsigned long long*)(misc + 2), (unsigned long long)__double_as_longlong(gm));
-        // L^-1 (lower) and z_g = L^-1 g replace U and g in the slab
-        acc[0] = i00; acc[1] = m10; acc[2] = m20; acc[3] = i11; acc[4] = m21; acc[5] = i22;
-        acc[6] = i00 * g0; acc[7] = m10 * g0 + i11 * g1; acc[8] = m20 * g0 + m21 * g1 + i22 * g2;
-      }
-    }
-    __syncthreads();
-    if (mode == 0) {
-      // ---------------- phase 3: W -> HBM (back-substitution), then Z = L^-1 W in place ----------------
-      for (uint32_t t = tid; t < np * NCMAX; t += 256) {   // camera columns: one (point, column) per thread
-        const uint32_t lp = t / NCMAX, j = t % NCMAX;
-        double* acc = slab + lp * 36;
-        const double w0 = acc[9 + j], w1 = acc[9 + NCMAX + j], w2 = acc[9 + 2 * NCMAX + j];
-        double* ga = d.ptacc + (size_t)d.v2_points[pt0 + lp] * 36 + 9;
-        ga[j] = w0; ga[NCMAX + j] = w1; ga[2 * NCMAX + j] = w2;
-        acc[9 + j] = acc[0] * w0; acc[9 + NCMAX + j] = acc[1] * w0 + acc[3] * w1; acc[9 + 2 * NCMAX + j] = acc[2] * w0 + acc[4] * w1 + acc[5] * w2;
-      }
-      for (uint32_t t = tid; t < ng * 6; t += 256) {       // pose columns: one (group, column) per thread
-        const uint32_t g = t / 6, j = t % 6;
-        const uint32_t lp = d.v2_slot[(size_t)ps * 256 + (g & 3u) * 64 + (g >> 2)] >> 16;
-        const double* acc = slab + lp * 36;
-        const double w0 = wv[j * 256 + g], w1 = wv[(6 + j) * 256 + g], w2 = wv[(12 + j) * 256 + g];
-        double* gw = d.Wv + (size_t)(gid0 + g) * 18;
-        gw[j] = w0; gw[6 + j] = w1; gw[12 + j] = w2;
-        wv[j * 256 + g] = acc[0] * w0; wv[(6 + j) * 256 + g] = acc[1] * w0 + acc[3] * w1; wv[(12 + j) * 256 + g] = acc[2] * w0 + acc[4] * w1 + acc[5] * w2;
-      }
-      __syncthreads();
-      // ---------------- phase 4: Schur products with exclusive ownership of destination sub-blocks ----------------
-      const uint32_t npp = nf * (nf + 1) / 2;
-      const uint32_t T_pp = npp * 4, T_cp = nf * 2, T_cc = 3, T_rp = nf, T_rc = 1;
-      for (uint32_t t = tid; t < T_pp + T_cp + T_cc + T_rp + T_rc; t += 256) {
-        if (t < T_pp) {
-          const uint32_t blk = t >> 2, hi = (t >> 1) & 1u, hj = t & 1u;
-          uint32_t a = (uint32_t)((sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
-          while (a * (a + 1) / 2 > blk) --a;
-          while ((a + 1) * (a + 2) / 2 <= blk) ++a;
-          const uint32_t bb = blk - a * (a + 1) / 2;
-          double acc9[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-          for (uint32_t lp = 0; lp < np; ++lp) {
-            const uint32_t sa = fmap[lp * NFm + a], sb = fmap[lp * NFm + bb];
-            if ((sa | sb) & 0x8000u) continue;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-              double za[3], zb[3];
-#pragma unroll
-              for (int i = 0; i < 3; ++i) { za[i] = wv[(r * 6 + 3 * hi + i) * 256 + sa]; zb[i] = wv[(r * 6 + 3 * hj + i) * 256 + sb]; }
-#pragma unroll
-              for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 3; ++j) acc9[i][j] += za[i] * zb[j];
-            }
-          }
-          double* dst = Spp + (size_t)blk * 36;
-#pragma unroll
-          for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) dst[(3 * hi + i) * 6 + 3 * hj + j] -= acc9[i][j];
-        } else if (t < T_pp + T_cp) {
-          const uint32_t u = t - T_pp, bb = u >> 1, hj = u & 1u;
-          double acc27[NCMAX][3];
-#pragma unroll
-          for (int i = 0; i < NCMAX; ++i) { acc27[i][0] = 0; acc27[i][1] = 0; acc27[i][2] = 0; }
-          for (uint32_t lp = 0; lp < np; ++lp) {
-            const uint32_t sb = fmap[lp * NFm + bb];
-            if (sb & 0x8000u) continue;
-            const double* zc = slab + lp * 36 + 9;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-              double zb[3];
-#pragma unroll
-              for (int j = 0; j < 3; ++j) zb[j] = wv[(r * 6 + 3 * hj + j) * 256 + sb];
-#pragma unroll
-              for (int i = 0; i < NC; ++i) { const double zi = zc[r * NCMAX + i]; acc27[i][0] += zi * zb[0]; acc27[i][1] += zi * zb[1]; acc27[i][2] += zi * zb[2]; }
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < NC; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) Scp[(size_t)i * 6 * NFm + 6 * bb + 3 * hj + j] -= acc27[i][j];
-        } else if (t < T_pp + T_cp + T_cc) {
-          const uint32_t jt = t - T_pp - T_cp;   // columns 3jt .. 3jt+2 of the camera block (lower part)
-          double accc[NCMAX][3];
-#pragma unroll
-          for (int i = 0; i < NCMAX; ++i) { accc[i][0] = 0; accc[i][1] = 0; accc[i][2] = 0; }
-          for (uint32_t lp = 0; lp < np; ++lp) {
-            const double* zc = slab + lp * 36 + 9;
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-              const double z0 = zc[r * NCMAX + 3 * jt], z1 = zc[r * NCMAX + 3 * jt + 1], z2 = zc[r * NCMAX + 3 * jt + 2];
-#pragma unroll
-              for (int i = 0; i < NC; ++i) { const double zi = zc[r * NCMAX + i]; accc[i][0] += zi * z0; accc[i][1] += zi * z1; accc[i][2] += zi * z2; }
-            }
-          }
-#pragma unroll
-          for (int i = 0; i < NC; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) { const int col = 3 * (int)jt + j; if (col <= i && col < NC) Scc[i * (i + 1) / 2 + col] -= accc[i][j]; }
-        } else if (t < T_pp + T_cp + T_cc + T_rp) {
-          const uint32_t bb = t - T_pp - T_cp - T_cc;
-          double a6[6] = {0, 0, 0, 0, 0, 0};
-          for (uint32_t lp = 0; lp < np; ++lp) {
-            const uint32_t sb = fmap[lp * NFm + bb];
-            if (sb & 0x8000u) continue;
-            const double* zg = slab + lp * 36 + 6;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-              for (int j = 0; j < 6; ++j) a6[j] += wv[(r * 6 + j) * 256 + sb] * zg[r];
-          }
-#pragma unroll
-          for (int j = 0; j < 6; ++j) vrhs[6 * bb + j] += a6[j];
-        } else {
-          double a9[NCMAX];
-#pragma unroll
-          for (int i = 0; i < NCMAX; ++i) a9[i] = 0;
-          for (uint32_t lp = 0; lp < np; ++lp) {
-            const double* zc = slab + lp * 36 + 9; const double* zg = slab + lp * 36 + 6;
-#pragma unroll
-            for (int r = 0; r < 3; ++r)
-#pragma unroll
-              for (int i = 0; i < NC; ++i) a9[i] += zc[r * NCMAX + i] * zg[r];
-          }
-#pragma unroll
-          for (int i = 0; i < NC; ++i) vrhs[6 * NFm + i] += a9[i];
-        }
-      }
-    }
-    __syncthreads();
-  }
-  // ---------------- camera x camera block, camera gradient, cost: wave reduction into LDS ----------------
-  {
-    int t = 0;
-#pragma unroll
-    for (int i = 0; i < NC; ++i) {
-#pragma unroll
-      for (int j = 0; j <= i; ++j) {
-        const double s = wave_sum(cc[t]);
-        if (lane == (uint32_t)(t & 63)) { if (mode == 0) atomicAdd(Scc + i * (i + 1) / 2 + j, s); if (i == j) atomicAdd(vhd + 6 * NFm + i, s); }
-        ++t;
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < NC; ++i) { const double s = wave_sum(gc[i]); if (lane == (uint32_t)i) atomicAdd(vgB + 6 * NFm + i, s); }
-    const double s = wave_sum(cost);
-    if (lane == 63) atomicAdd(misc + 0, s);
-  }
-  __syncthreads();
-  // ---------------- flush the window into the global reduced system (contiguous runs) ----------------
-  const uint32_t F6 = 6 * d.F, camrow = 3 * d.Q, camcol = F6 + 3 * d.Q;
-  for (uint32_t i = tid; i < 6 * nf; i += 256) atomicAdd(d.hdiag + 6 * flo + i, vhd[i]);
-  if (tid < (uint32_t)NC) atomicAdd(d.hdiag + camcol + tid, vhd[6 * NFm + tid]);
-  if (mode == 0) {
-    const uint32_t npp = nf * (nf + 1) / 2;
-    for (uint32_t i = tid; i < npp * 36; i += 256) {
-      const uint32_t blk = i / 36, e = i % 36;
-      uint32_t a = (uint32_t)((sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
-      while (a * (a + 1) / 2 > blk) --a;
-      while ((a + 1) * (a + 2) / 2 <= blk) ++a;
-      const uint32_t bb = blk - a * (a + 1) / 2, dd = a - bb;
-      const double v = Spp[i];
-      if (dd <= d.bw && v != 0.0 && !(dd == 0 && (e % 6) > (e / 6))) atomicAdd(d.Sband + ((size_t)(flo + a) * (d.bw + 1) + dd) * 36 + e, v);
-    }
-    for (uint32_t i = tid; i < (uint32_t)NC * 6 * nf; i += 256) {
-      const uint32_t j = i / (6 * nf), cidx = i % (6 * nf);
-      atomicAdd(d.Sarrow + (size_t)(camrow + j) * d.ld + 6 * flo + cidx, Scp[(size_t)j * 6 * NFm + cidx]);
-    }
-    if (tid < (uint32_t)NCC) {
-      uint32_t i = 0; while ((i + 1) * (i + 2) / 2 <= tid) ++i;
-      const uint32_t j = tid - i * (i + 1) / 2;
-      atomicAdd(d.Sarrow + (size_t)(camrow + i) * d.ld + camcol + j, Scc[tid]);
-    }
-    for (uint32_t i = tid; i < 6 * nf; i += 256) { atomicAdd(d.gB + 6 * flo + i, vgB[i]); atomicAdd(d.rhsacc + 6 * flo + i, vrhs[i]); }
-    if (tid < (uint32_t)NC) { atomicAdd(d.gB + camcol + tid, vgB[6 * NFm + tid]); atomicAdd(d.rhsacc + camcol + tid, vrhs[6 * NFm + tid]); }
-    if (tid == 0) {
-      atomicAdd(d.scal + SCAL_COST, misc[0]);
-      if (misc[1] != 0.0) atomicAdd(d.scal + SCAL_BAD_U, misc[1]);
-      atomicMax((unsigned long long*)(d.scal + SCAL_GMAX0 + d.rank), *(unsigned long long*)(misc + 2));
-    }
-  }
-}
+}  // namespace lifcal
+#include "sweep2.hpp"   // k_sweep2: the LDS-window fused sweep (regular points)
+namespace lifcal {
 
 // ---------------------------------------------------------------------------------------------
 // distance constraints: r = (|Pi - Pj| - dist) / (sigma + 1e-6), squared loss; c_j is always promoted

@@ -436,7 +436,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
     U(t, L.gid_fr); d.gid_fr = t; U(t, L.slot_gid); d.slot_gid = t; U(t, L.special_owned); d.special_owned = t;
     U(t, L.blk_pass0); d.blk_pass0 = t; U(t, L.blk_flo); d.blk_flo = t; U(t, L.blk_nf); d.blk_nf = t;
     U(t, L.pass_pt0); d.pass_pt0 = t; U(t, L.pass_np); d.pass_np = t; U(t, L.pass_gid0); d.pass_gid0 = t; U(t, L.pass_ng); d.pass_ng = t;
-    U(t, L.v2_points); d.v2_points = t; U(t, L.v2_slot); d.v2_slot = t; U(t, L.v2_tile_row0); d.v2_tile_row0 = t; U(t, L.v2_lens); d.v2_lens = t; }
+    U(t, L.v2_points); d.v2_points = t; U(t, L.v2_ptinfo); d.v2_ptinfo = t; U(t, L.v2_slot); d.v2_slot = t; U(t, L.v2_tile_row0); d.v2_tile_row0 = t; U(t, L.v2_lens); d.v2_lens = t; }
   { double* t; U(t, L.v2_u); d.v2_u = t; U(t, L.v2_v); d.v2_v = t; }
   { uint32_t *a, *b, *c; U(a, L.v2f_pt); U(b, L.v2f_fr); U(c, L.v2f_cnt);
     h->ts2 = TileSet{4 * L.n_passes, d.v2_tile_row0, a, b, c, d.v2_lens, d.v2_u, d.v2_v}; }
@@ -465,6 +465,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   A(h->red_block, h->red_count);
   d.Sband = h->red_block; d.Sarrow = d.Sband + n_band; d.rhsacc = d.Sarrow + n_arrow; d.gB = d.rhsacc + d.n_red; d.hdiag = d.gB + d.n_red; d.scal = d.hdiag + d.n_red;
   A(d.sig_red, d.n_red); A(d.lam_red, d.n_red); A(d.delta_red, d.n_red); A(d.Linv, (size_t)d.F * 36 + 36);
+  A(d.dbg, (size_t)std::max(1u, d.n_blocks) * 8);
   A(d.step, ST_N); A(h->partial, 8); A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->pts_gather, 3 * (size_t)d.P);
   // Cholesky panel: LDS when it fits (<= 64 KiB by default launch limits), else a global scratch
   const size_t panel_rows = 6 * (size_t)d.bw + d.NA + 1;
@@ -518,6 +519,17 @@ int lifcal_ba_comm_init_rccl(lifcal_ba_handle* h, const void* unique_id128) {
   if (g_rccl.CommInitRank(&h->comm, h->opt.world_size, id, h->opt.rank) != 0) { g_last_error = "ncclCommInitRank failed"; h->comm = nullptr; return LIFCAL_BA_ERR_COMM; }
   return 0;
 }
+
+#ifdef LIFCAL_STAMPS
+// diagnostic build only: copies the per-block phase cycle counters of the last k_sweep2 launch (8 per block)
+extern "C" int lifcal_ba_debug_stamps(lifcal_ba_handle* h, unsigned long long* out, uint32_t max_blocks) {
+  if (!h || !out) return LIFCAL_BA_ERR_INVALID_ARG;
+  const uint32_t n = std::min(max_blocks, h->d.n_blocks);
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  HIP_TRY(hipMemcpy(out, h->d.dbg, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return (int)n;
+}
+#endif
 
 int lifcal_ba_get_info(lifcal_ba_handle* h, lifcal_ba_info* out) {
   if (!h || !out) return LIFCAL_BA_ERR_INVALID_ARG;

@@ -65,13 +65,14 @@ struct Plan {
   // ---- v2 (LDS-window) path: regular points only -------------------------------------------------
   // block  = one workgroup: contiguous range of points whose frames fit a window of <= NF_MAX frames
   // pass   = <= 256 groups / <= 64 points of a block (4 tiles, group g -> wave g%4, lane g/4)
-  static constexpr uint32_t NF_MAX = 20, NP_MAX = 64, PASS_GROUPS = 256;
+  static constexpr uint32_t NF_MAX = 20, NP_MAX = 64, PASS_GROUPS = 256, ZD_DOUBLES = 8192;
   uint32_t n_blocks = 0, n_passes = 0, max_block_nf = 0;
   std::vector<uint32_t> blk_pass0;     // n_blocks+1
   std::vector<uint32_t> blk_flo, blk_nf;
   std::vector<uint32_t> pass_pt0, pass_np, pass_gid0, pass_ng;   // per pass: first entry in v2_points, #points, first gid, #groups
   std::vector<uint32_t> v2_points;     // point ids in processing order
-  std::vector<uint32_t> v2_slot;       // per (pass*256 + wave*64 + lane): cnt | lf<<8 | lp<<16 ; 0 = idle
+  std::vector<uint32_t> v2_ptinfo;     // per entry of v2_points: first pass-local group | number of groups << 16
+  std::vector<uint32_t> v2_slot;       // per (pass*256 + wave*64 + lane): cnt | lf<<8 | lp<<16 | rep<<24 ; 0 = idle
   std::vector<uint32_t> v2f_pt, v2f_fr, v2f_cnt;   // the same slots, flat (value-only kernels: cost, statistics)
   std::vector<uint32_t> v2_tile_row0;  // 4*n_passes+1
   std::vector<double> v2_u, v2_v; std::vector<uint32_t> v2_lens, v2_src;
@@ -253,7 +254,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   }
 
   // --- v2 blocks / passes from the regular points (already in point order) ---
-  L.v2_points.clear(); L.blk_pass0.assign(1, 0); L.blk_flo.clear(); L.blk_nf.clear();
+  L.v2_points.clear(); L.v2_ptinfo.clear(); L.blk_pass0.assign(1, 0); L.blk_flo.clear(); L.blk_nf.clear();
   L.pass_pt0.clear(); L.pass_np.clear(); L.pass_gid0.clear(); L.pass_ng.clear();
   L.n_obs_v2 = 0;
   {
@@ -274,16 +275,18 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
       }
       L.blk_flo.push_back(flo); L.blk_nf.push_back(fhi - flo + 1);
       L.max_block_nf = std::max(L.max_block_nf, fhi - flo + 1);
-      // passes inside the block
+      // passes inside the block; the dense Z matrix of a pass (3 np rows x padded window columns) must fit its LDS budget
+      const uint32_t ncolp = ((6 * (fhi - flo + 1) + (uint32_t)L.nc + 1) + 15u) & ~15u;
+      const uint32_t np_cap = std::max(1u, std::min<uint32_t>(Plan::NP_MAX, ((Plan::ZD_DOUBLES / ncolp) & ~3u) / 3));
       size_t a = i;
       while (a < j) {
         uint32_t ng = 0, np = 0; size_t e = a;
         // a pass covers one contiguous run of gids (a special point's groups in between end the pass)
-        while (e < j && np < Plan::NP_MAX && ng + L.pt_nslots[reg[e]] <= Plan::PASS_GROUPS &&
+        while (e < j && np < np_cap && ng + L.pt_nslots[reg[e]] <= Plan::PASS_GROUPS &&
                (e == a || L.pt_slot0[reg[e]] == L.pt_slot0[reg[e - 1]] + L.pt_nslots[reg[e - 1]])) { ng += L.pt_nslots[reg[e]]; ++np; ++e; }
         L.pass_pt0.push_back((uint32_t)L.v2_points.size()); L.pass_np.push_back(np);
         L.pass_gid0.push_back(L.pt_slot0[reg[a]]); L.pass_ng.push_back(ng);
-        for (size_t k = a; k < e; ++k) L.v2_points.push_back(reg[k]);
+        { uint32_t g0 = 0; for (size_t k = a; k < e; ++k) { L.v2_points.push_back(reg[k]); L.v2_ptinfo.push_back(g0 | (L.pt_nslots[reg[k]] << 16)); g0 += L.pt_nslots[reg[k]]; } }
         a = e;
       }
       L.blk_pass0.push_back((uint32_t)L.pass_pt0.size());
@@ -314,15 +317,18 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     L.v2_u.assign(rows * 64, 0.0); L.v2_v.assign(rows * 64, 0.0); L.v2_lens.assign(rows * 64, 0); L.v2_src.assign(rows * 64, UINT32_MAX);
     for (uint32_t b = 0; b < L.n_blocks; ++b)
       for (uint32_t ps = L.blk_pass0[b]; ps < L.blk_pass0[b + 1]; ++ps) {
-        // local point index of each group
+        // local point index of each group; replica = occurrence rank of the group's frame inside its wave
         uint32_t lp = 0, left = 0;
+        std::vector<uint32_t> occ(4 * (Plan::NF_MAX + 1), 0);
         for (uint32_t g = 0; g < pass_groups[ps].size(); ++g) {
           const Group& G = groups[pass_groups[ps][g]];
           if (g == 0) { lp = 0; left = L.pt_nslots[G.pt]; }
           else if (left == 0) { ++lp; left = L.pt_nslots[G.pt]; }
           --left;
           const uint32_t w = g % 4, l = g / 4;
-          L.v2_slot[(size_t)ps * 256 + w * 64 + l] = G.n | ((G.fr - L.blk_flo[b]) << 8) | (lp << 16);
+          const uint32_t lfl = G.fr - L.blk_flo[b];
+          const uint32_t rep = std::min(255u, occ[w * (Plan::NF_MAX + 1) + lfl]++);
+          L.v2_slot[(size_t)ps * 256 + w * 64 + l] = std::min(G.n, 255u) | (lfl << 8) | (lp << 16) | (rep << 24);
           L.v2f_pt[(size_t)ps * 256 + w * 64 + l] = G.pt; L.v2f_fr[(size_t)ps * 256 + w * 64 + l] = G.fr; L.v2f_cnt[(size_t)ps * 256 + w * 64 + l] = G.n;
           for (uint32_t j = 0; j < G.n; ++j) {
             const size_t at = ((size_t)L.v2_tile_row0[(size_t)ps * 4 + w] + j) * 64 + l;

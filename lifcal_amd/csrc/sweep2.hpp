@@ -1,0 +1,444 @@
+// sweep2.hpp — k_sweep2: the fused Jacobian + Schur sweep for "regular" points (included by kernels.hpp).
+//
+// One WORKGROUP owns a contiguous range of points ("block") whose frames fit a window of nf <= 20 frames.
+// Everything the block accumulates lives in LDS until one flush at the end:
+//   Spp  pose x pose blocks of the window (lower block triangle, 36 doubles each)
+//   Scp  camera x pose, Scc camera x camera, vec = gradient / diagonal / rhs of the window + camera
+//   slab U(6) g(3) per point of the current pass, Zd = dense (3 np) x (window columns) matrix of the pass
+// A pass = <= 256 groups (group g -> wave g%4, lane g/4).  Per pass:
+//   (1) lanes walk their observations (residual, analytic Jacobian, Cauchy weight) and add their rotated blocks with
+//       LDS f64 atomics; W_pose goes straight to HBM (back-substitution) and into its cell of Zd,
+//   (2) one thread per point damps and factors U = L L^T (ceres LevenbergMarquardtStrategy + InvertPSDMatrix<3>),
+//   (3) Zd <- L^-1 W row-wise; rhs column = L^-1 g,
+//   (4) window -= Zd^T Zd on the f64 matrix cores (v_mfma_f64_16x16x4_f64): every 16x16 output tile is owned by one
+//       wave, so the point elimination W^T U^-1 W (and W^T U^-1 g, the last column) needs no atomics at all.
+// mode 1 ("diagonal only", iteration 0): just the Hessian diagonal for the Jacobi scaling.
+// Replaces, per LM iteration: ceres autodiff evaluation of OurCostFunctionBundle (reference
+// src/BundleAdjustment/BundleAdjustment.h:120-222) + SchurEliminator::Eliminate (out of tree).
+#pragma once
+
+namespace lifcal {
+
+constexpr uint32_t ZD_DOUBLES = 8192;   // LDS doubles reserved for the dense Z matrix of one pass (64 KiB)
+
+constexpr uint32_t FRV = 27 + 6 * NCMAX;   // frame-level values a group emits: pose x pose lower (21) + pose gradient (6) + camera x pose (6 NC)
+constexpr uint32_t LDS_LIMIT_DOUBLES = 160 * 1024 / 8;
+
+struct V2Lds {
+  uint32_t nfm, nrep, off_cp, off_cc, off_vec, off_fr, off_slab, off_zd, off_misc, total;
+  __host__ __device__ explicit V2Lds(uint32_t nfmax) {
+    nfm = nfmax;
+    const uint32_t npp = nfm * (nfm + 1) / 2;
+    off_cp = npp * 36; off_cc = off_cp + NCMAX * 6 * nfm; off_vec = off_cc + 48;
+    off_fr = off_vec + 3 * (6 * nfm + NCMAX + 3);
+    off_fr = (off_fr + 1) & ~1u;
+    // replicated frame accumulators [rep][value][frame]: as many replicas (<= 8) as the 160 KiB LDS allows
+    const uint32_t fixed = off_fr + 64 * 12 + ZD_DOUBLES + 8;
+    uint32_t r = (LDS_LIMIT_DOUBLES - fixed) / (FRV * nfm);
+    nrep = r < 1 ? 1 : (r > 8 ? 8 : r);
+    off_slab = off_fr + nrep * FRV * nfm;
+    off_zd = off_slab + 64 * 12; off_misc = off_zd + ZD_DOUBLES; total = off_misc + 8;
+  }
+};
+
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+
+// wave64 sum through DPP (row_shr 1,2,4,8 + row_bcast 15/31); the total ends up in lane 63
+template <int CTRL, int ROW_MASK>
+LIFCAL_DEV double dpp_add_step(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+  return v + __hiloint2double(hi2, lo2);
+}
+LIFCAL_DEV double wave_sum_dpp(double v) {
+  v = dpp_add_step<0x111, 0xf>(v);  // row_shr:1
+  v = dpp_add_step<0x112, 0xf>(v);  // row_shr:2
+  v = dpp_add_step<0x114, 0xf>(v);  // row_shr:4
+  v = dpp_add_step<0x118, 0xf>(v);  // row_shr:8   -> lane 15 of every row holds the row sum
+  v = dpp_add_step<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add_step<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave sum
+  return v;
+}
+
+#ifdef LIFCAL_STAMPS
+#define STAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[i] += t_ - st_last; st_last = t_; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+
+template <int NR, bool TAN, bool ADJ>
+__global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) {
+  constexpr int NC = 5 + NR + (TAN ? 2 : 0);
+  constexpr int NCC = NC * (NC + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const V2Lds lay(d.v2_nfmax);
+  const uint32_t NFm = lay.nfm, vlen = 6 * NFm + NCMAX + 3;
+  double* Spp = sm; double* Scp = sm + lay.off_cp; double* Scc = sm + lay.off_cc;
+  double* vgB = sm + lay.off_vec; double* vhd = vgB + vlen; double* vrhs = vhd + vlen;
+  double* Fr = sm + lay.off_fr;       // [rep][value][frame] replicated frame-level accumulators
+  double* slab = sm + lay.off_slab;   // per point of the pass: [0..5] U -> L^-1, [6..8] g
+  double* Zd = sm + lay.off_zd;
+  double* misc = sm + lay.off_misc;   // [0] cost, [1] bad-U count, [2] max |g_p| (as bits)
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+  const uint32_t b = blockIdx.x;
+  const uint32_t flo = d.blk_flo[b], nf = d.blk_nf[b];
+  const uint32_t ncol = 6 * nf + NC + 1, ncolp = (ncol + 15u) & ~15u;   // pose | camera | rhs, padded to MFMA tiles
+  const CamConsts c = *d.camc;
+#ifdef LIFCAL_STAMPS
+  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+  if (tid == 0) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); }
+#endif
+  for (uint32_t i = tid; i < lay.off_slab; i += 256) sm[i] = 0.0;
+  if (tid < 8) misc[tid] = 0.0;
+  double cc[NCC], gc[NC], cost = 0.0;
+#pragma unroll
+  for (int i = 0; i < NCC; ++i) cc[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < NC; ++i) gc[i] = 0.0;
+
+  for (uint32_t ps = d.blk_pass0[b]; ps < d.blk_pass0[b + 1]; ++ps) {
+    const uint32_t np = d.pass_np[ps], pt0 = d.pass_pt0[ps], gid0 = d.pass_gid0[ps];
+    const uint32_t krows = (3 * np + 3u) & ~3u;   // K of the product, multiple of 4
+    for (uint32_t i = tid; i < 64 * 12; i += 256) slab[i] = 0.0;
+    if (mode == 0) for (uint32_t i = tid; i < krows * ncolp; i += 256) Zd[i] = 0.0;
+    __syncthreads();
+    STAMP(0);
+    // ---------------- phase 1: observations -> LDS blocks ----------------
+    {
+      const uint32_t si = d.v2_slot[(size_t)ps * 256 + w * 64 + lane];
+      const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = (si >> 16) & 0xFFu, rep = (si >> 24) % lay.nrep;
+      const uint32_t g = lane * 4 + w;
+      const uint32_t tile = ps * 4 + w;
+      const uint32_t row0 = d.v2_tile_row0[tile], kmax = d.v2_tile_row0[tile + 1] - row0;
+      const uint32_t pt = d.v2_points[pt0 + (cnt ? lp : 0)], fr = flo + lf;
+      double R[9], Y[3], c0, s0;
+      GroupConsts gcn;
+      {
+        const double* ft = d.ft + (size_t)fr * FRAME_STRIDE;
+        const double* P = d.pts + 3 * (size_t)pt;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = ft[k];
+        const double P0 = P[0], P1 = P[1], P2 = P[2];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) Y[k] = R[3 * k] * P0 + R[3 * k + 1] * P1 + R[3 * k + 2] * P2;
+        c0 = ft[12]; s0 = ft[13];
+        group_prepare(c, Y[0] + ft[9], Y[1] + ft[10], Y[2] + ft[11], gcn);
+      }
+      double A[6] = {0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0}, C[3][NC];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < NC; ++j) C[i][j] = 0.0;
+      for (uint32_t k = 0; k < kmax; ++k) {
+        if (k < cnt) {
+          const size_t at = ((size_t)row0 + k) * 64 + lane;
+          const double u = d.v2_u[at], v = d.v2_v[at];
+          const double* L = d.lt + (size_t)d.v2_lens[at] * LENS_STRIDE;
+          double r[2], Jq[2][3], Jc[2][NC];
+          obs_eval<NR, TAN, ADJ>(c, gcn, L, u, v, r, Jq, Jc);
+          const double sq = r[0] * r[0] + r[1] * r[1];
+          if (d.robust) {  // ceres::CauchyLoss + Corrector with rho'' < 0: scale r and J by sqrt(rho')
+            const double sum = 1.0 + sq * c.loss_c;
+            const double inv = 1.0 / sum;
+            cost += 0.5 * c.loss_b * log(sum);
+            const double sc = sqrt(fmax(inv, 2.2250738585072014e-308));
+            r[0] *= sc; r[1] *= sc;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+              for (int j = 0; j < 3; ++j) Jq[a][j] *= sc;
+#pragma unroll
+              for (int j = 0; j < NC; ++j) Jc[a][j] *= sc;
+            }
+          } else {
+            cost += 0.5 * sq;
+          }
+#pragma unroll
+          for (int a = 0; a < 2; ++a) {
+            A[0] += Jq[a][0] * Jq[a][0]; A[1] += Jq[a][0] * Jq[a][1]; A[2] += Jq[a][0] * Jq[a][2];
+            A[3] += Jq[a][1] * Jq[a][1]; A[4] += Jq[a][1] * Jq[a][2]; A[5] += Jq[a][2] * Jq[a][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) bv[i] += Jq[a][i] * r[a];
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+              for (int j = 0; j < NC; ++j) C[i][j] += Jq[a][i] * Jc[a][j];
+            int t = 0;
+#pragma unroll
+            for (int i = 0; i < NC; ++i) {
+              gc[i] += Jc[a][i] * r[a];
+#pragma unroll
+              for (int j = 0; j <= i; ++j) cc[t++] += Jc[a][i] * Jc[a][j];
+            }
+          }
+        }
+      }
+      STAMP(7);
+      if (cnt > 0) {
+        const double Am[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
+        // Gr = [e_x x Y, (0,c0,s0) x Y, R[:,2] x Y]: d(R P)/d(a0,a1,a2)
+        const double n0 = R[2], n1 = R[5], n2 = R[8];
+        const double Gr[3][3] = {{0.0, c0 * Y[2] - s0 * Y[1], n1 * Y[2] - n2 * Y[1]},
+                                 {-Y[2], s0 * Y[0], n2 * Y[0] - n0 * Y[2]},
+                                 {Y[1], -c0 * Y[0], n0 * Y[1] - n1 * Y[0]}};
+        double AG[3][3], GAG[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) AG[i][j] = Am[i][0] * Gr[0][j] + Am[i][1] * Gr[1][j] + Am[i][2] * Gr[2][j];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) GAG[i][j] = Gr[0][i] * AG[0][j] + Gr[1][i] * AG[1][j] + Gr[2][i] * AG[2][j];
+        // frame-level values go to this lane's replica, value-major: every lane of the wave instruction hits its own address
+        double* fr_acc = Fr + (size_t)rep * FRV * NFm + lf;
+        {
+          int vi = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int bb = 0; bb <= a; ++bb) {
+              double v;
+              if (a < 3) v = GAG[a][bb]; else if (bb < 3) v = AG[a - 3][bb]; else v = Am[a - 3][bb - 3];
+              atomicAdd(fr_acc + (size_t)vi * NFm, v);
+              ++vi;
+            }
+#pragma unroll
+          for (int a = 0; a < 3; ++a) atomicAdd(fr_acc + (size_t)(21 + a) * NFm, Gr[0][a] * bv[0] + Gr[1][a] * bv[1] + Gr[2][a] * bv[2]);
+#pragma unroll
+          for (int a = 0; a < 3; ++a) atomicAdd(fr_acc + (size_t)(24 + a) * NFm, bv[a]);
+          if (mode == 0) {
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+#pragma unroll
+              for (int ci = 0; ci < 3; ++ci) atomicAdd(fr_acc + (size_t)(27 + j * 6 + ci) * NFm, C[0][j] * Gr[0][ci] + C[1][j] * Gr[1][ci] + C[2][j] * Gr[2][ci]);
+#pragma unroll
+              for (int ci = 0; ci < 3; ++ci) atomicAdd(fr_acc + (size_t)(27 + j * 6 + 3 + ci) * NFm, C[ci][j]);
+            }
+          }
+        }
+        double AR[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) AR[i][j] = Am[i][0] * R[j] + Am[i][1] * R[3 + j] + Am[i][2] * R[6 + j];
+        double* acc = slab + lp * 12;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+          for (int j = 0; j <= i; ++j) {
+            const double u_ij = R[i] * AR[0][j] + R[3 + i] * AR[1][j] + R[6 + i] * AR[2][j];
+            const int pos = (i == 0) ? 0 : (i == 1 ? (j == 0 ? 1 : 3) : (j == 0 ? 2 : (j == 1 ? 4 : 5)));
+            atomicAdd(acc + pos, u_ij);
+          }
+        }
+        if (mode == 0) {
+          double* gw = d.Wv + (size_t)(gid0 + g) * 18;   // W_pose of this group: straight to HBM for the back-substitution
+#pragma unroll
+          for (int i = 0; i < 3; ++i) {
+            atomicAdd(acc + 6 + i, R[i] * bv[0] + R[3 + i] * bv[1] + R[6 + i] * bv[2]);
+            double* zrow = Zd + (size_t)(3 * lp + i) * ncolp;
+#pragma unroll
+            for (int j = 0; j < NC; ++j) atomicAdd(zrow + 6 * nf + j, R[i] * C[0][j] + R[3 + i] * C[1][j] + R[6 + i] * C[2][j]);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const double wij = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j]; zrow[6 * lf + j] = wij; gw[i * 6 + j] = wij; }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { const double wij = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j]; zrow[6 * lf + 3 + j] = wij; gw[i * 6 + 3 + j] = wij; }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    STAMP(1);
+    // ---------------- phase 2: one thread per point: damp, factor U = L L^T ----------------
+    if (tid < np) {
+      const uint32_t p = d.v2_points[pt0 + tid];
+      double* acc = slab + tid * 12;
+      double U0 = acc[0], U1 = acc[1], U2 = acc[2], U3 = acc[3], U4 = acc[4], U5 = acc[5];
+      if (mode == 1) {
+        double* ga = d.ptacc + (size_t)p * 36;
+        ga[0] = U0; ga[3] = U3; ga[5] = U5;
+      } else {
+        const double g0 = acc[6], g1 = acc[7], g2 = acc[8];
+        double lam[3];
+        {
+          const double h[3] = {U0, U3, U5};
+#pragma unroll
+          for (int k = 0; k < 3; ++k) { const double sg = d.sigP[3 * (size_t)p + k]; lam[k] = fmin(fmax(h[k] * sg * sg, d.lm_min), d.lm_max) / (radius * sg * sg); }
+        }
+        U0 += lam[0]; U3 += lam[1]; U5 += lam[2];
+        bool ok = true;
+        double l00 = U0; ok = ok && (l00 > 0.0); l00 = sqrt(l00);
+        const double l10 = U1 / l00, l20 = U2 / l00;
+        double l11 = U3 - l10 * l10; ok = ok && (l11 > 0.0); l11 = sqrt(l11);
+        const double l21 = (U4 - l20 * l10) / l11;
+        double l22 = U5 - l20 * l20 - l21 * l21; ok = ok && (l22 > 0.0); l22 = sqrt(l22);
+        double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+        double m10 = -l10 * i00 * i11, m21 = -l21 * i11 * i22, m20 = -(l20 * i00 + l21 * m10) * i22;
+        if (!ok) { i00 = i11 = i22 = m10 = m21 = m20 = 0.0; atomicAdd(misc + 1, 1.0); }
+        double* gu = d.Uinv + 9 * (size_t)p;
+        const double v00 = i00 * i00 + m10 * m10 + m20 * m20, v01 = m10 * i11 + m20 * m21, v02 = m20 * i22;
+        const double v11 = i11 * i11 + m21 * m21, v12 = m21 * i22, v22 = i22 * i22;
+        gu[0] = v00; gu[1] = v01; gu[2] = v02; gu[3] = v01; gu[4] = v11; gu[5] = v12; gu[6] = v02; gu[7] = v12; gu[8] = v22;
+        double* gl = d.lamP + 3 * (size_t)p; gl[0] = lam[0]; gl[1] = lam[1]; gl[2] = lam[2];
+        double* ga = d.ptacc + (size_t)p * 36;
+        ga[6] = g0; ga[7] = g1; ga[8] = g2;
+        const double gm = fmax(fabs(g0), fmax(fabs(g1), fabs(g2)));
+        atomicMax((unsigned long long*)(misc + 2), (unsigned long long)__double_as_longlong(gm));
+        acc[0] = i00; acc[1] = m10; acc[2] = m20; acc[3] = i11; acc[4] = m21; acc[5] = i22;
+        // rhs column of Zd: L^-1 g
+        double* z0 = Zd + (size_t)(3 * tid) * ncolp + (ncol - 1);
+        z0[0] = i00 * g0; z0[ncolp] = m10 * g0 + i11 * g1; z0[2 * ncolp] = m20 * g0 + m21 * g1 + i22 * g2;
+      }
+    }
+    __syncthreads();
+    STAMP(2);
+    if (mode == 0) {
+      // ---------------- phase 3: camera part of W -> HBM, then Z = L^-1 W in place (pose + camera columns) ----------------
+      const uint32_t nwc = ncol - 1;
+      for (uint32_t t = tid; t < np * nwc; t += 256) {
+        const uint32_t lp = t / nwc, cidx = t % nwc;
+        const double* acc = slab + lp * 12;
+        double* z = Zd + (size_t)(3 * lp) * ncolp + cidx;
+        const double w0 = z[0], w1 = z[ncolp], w2 = z[2 * ncolp];
+        if (cidx >= 6 * nf) {
+          double* ga = d.ptacc + (size_t)d.v2_points[pt0 + lp] * 36 + 9 + (cidx - 6 * nf);
+          ga[0] = w0; ga[NCMAX] = w1; ga[2 * NCMAX] = w2;
+        }
+        z[0] = acc[0] * w0; z[ncolp] = acc[1] * w0 + acc[3] * w1; z[2 * ncolp] = acc[2] * w0 + acc[4] * w1 + acc[5] * w2;
+      }
+      __syncthreads();
+      STAMP(3);
+      // ---------------- phase 4: window -= Zd^T Zd on the f64 matrix cores, one 16x16 output tile per wave at a time ----------------
+      const uint32_t ntile = ncolp >> 4;
+      const uint32_t ntri = ntile * (ntile + 1) / 2;
+      const uint32_t li = lane & 15u, lk = lane >> 4;
+      constexpr int NT = 6;   // independent accumulator tiles per wave: hides the MFMA accumulate latency and the LDS reads
+      for (uint32_t t0 = w; t0 < ntri; t0 += 4 * NT) {
+        uint32_t tis[NT], tjs[NT];
+        const double* za[NT]; const double* zb[NT];
+        v4f64 accm[NT];
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          uint32_t t = t0 + 4 * q; if (t >= ntri) t = t0;   // surplus slots recompute tile t0 and are not written back
+          uint32_t ti = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+          while (ti * (ti + 1) / 2 > t) --ti;
+          while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+          tis[q] = ti; tjs[q] = t - ti * (ti + 1) / 2;
+          // A operand: lane holds A[i = lane&15][k = lane>>4] = Zd[k0 + k][16 ti + i]; B operand: Zd[k0 + k][16 tj + j]
+          za[q] = Zd + (size_t)lk * ncolp + tis[q] * 16 + li;
+          zb[q] = Zd + (size_t)lk * ncolp + tjs[q] * 16 + li;
+          accm[q] = v4f64{0.0, 0.0, 0.0, 0.0};
+        }
+        for (uint32_t k0 = 0; k0 < krows; k0 += 4) {
+          double av[NT], bvv[NT];
+#pragma unroll
+          for (int q = 0; q < NT; ++q) { av[q] = za[q][(size_t)k0 * ncolp]; bvv[q] = zb[q][(size_t)k0 * ncolp]; }
+#pragma unroll
+          for (int q = 0; q < NT; ++q) accm[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bvv[q], accm[q], 0, 0, 0);
+        }
+        // f64 C/D layout: D[row = (lane>>4) + 4 r][col = lane&15]; row indexes the ti tile, col the tj tile
+#pragma unroll
+        for (int q = 0; q < NT; ++q) {
+          if (t0 + 4 * q >= ntri) continue;
+          const uint32_t cj = tjs[q] * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const uint32_t ci = tis[q] * 16 + lk + 4 * r;
+            const double dv = accm[q][r];
+            if (ci >= ncol || cj >= ncol || ci < cj) continue;
+            if (ci < 6 * nf) {            // pose x pose
+              const uint32_t lfi = ci / 6, lfj = cj / 6;
+              Spp[(size_t)(lfi * (lfi + 1) / 2 + lfj) * 36 + (ci % 6) * 6 + (cj % 6)] -= dv;
+            } else if (ci < ncol - 1) {   // camera row
+              const uint32_t jc = ci - 6 * nf;
+              if (cj < 6 * nf) Scp[(size_t)jc * 6 * NFm + cj] -= dv;
+              else Scc[jc * (jc + 1) / 2 + (cj - 6 * nf)] -= dv;
+            } else if (cj < ncol - 1) {   // rhs row: W^T U^-1 g
+              if (cj < 6 * nf) vrhs[cj] += dv; else vrhs[6 * NFm + (cj - 6 * nf)] += dv;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+    STAMP(4);
+  }
+  // ---------------- camera x camera block, camera gradient, cost: DPP wave reduction into LDS ----------------
+  {
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+#pragma unroll
+      for (int j = 0; j <= i; ++j) {
+        const double s = wave_sum_dpp(cc[t]);
+        if (lane == 63) { if (mode == 0) atomicAdd(Scc + i * (i + 1) / 2 + j, s); if (i == j) atomicAdd(vhd + 6 * NFm + i, s); }
+        ++t;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) { const double s = wave_sum_dpp(gc[i]); if (lane == 63) atomicAdd(vgB + 6 * NFm + i, s); }
+    const double s = wave_sum_dpp(cost);
+    if (lane == 63) atomicAdd(misc + 0, s);
+  }
+  __syncthreads();
+  // fold the replicas: pose x pose diagonal blocks (+ Hessian diagonal), pose gradient, camera x pose
+  for (uint32_t i = tid; i < FRV * nf; i += 256) {
+    const uint32_t v = i / nf, lf = i % nf;
+    double sacc = 0.0;
+    for (uint32_t r = 0; r < lay.nrep; ++r) sacc += Fr[((size_t)r * FRV + v) * NFm + lf];
+    if (v < 21) {
+      uint32_t a = 0; while ((a + 1) * (a + 2) / 2 <= v) ++a;
+      const uint32_t bb = v - a * (a + 1) / 2;
+      Spp[(size_t)(lf * (lf + 1) / 2 + lf) * 36 + a * 6 + bb] += sacc;
+      if (a == bb) vhd[6 * lf + a] += sacc;
+    } else if (v < 27) {
+      vgB[6 * lf + (v - 21)] += sacc;
+    } else if (mode == 0 && v < 27 + 6 * (uint32_t)NC) {
+      const uint32_t j = (v - 27) / 6, ci = (v - 27) % 6;
+      Scp[(size_t)j * 6 * NFm + 6 * lf + ci] += sacc;
+    }
+  }
+  __syncthreads();
+  STAMP(5);
+  // ---------------- flush the window into the global reduced system (contiguous runs) ----------------
+  const uint32_t F6 = 6 * d.F, camrow = 3 * d.Q, camcol = F6 + 3 * d.Q;
+  for (uint32_t i = tid; i < 6 * nf; i += 256) atomicAdd(d.hdiag + 6 * flo + i, vhd[i]);
+  if (tid < (uint32_t)NC) atomicAdd(d.hdiag + camcol + tid, vhd[6 * NFm + tid]);
+  if (mode == 0) {
+    const uint32_t npp = nf * (nf + 1) / 2;
+    for (uint32_t i = tid; i < npp * 36; i += 256) {
+      const uint32_t blk = i / 36, e = i % 36;
+      uint32_t a = (uint32_t)((sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
+      while (a * (a + 1) / 2 > blk) --a;
+      while ((a + 1) * (a + 2) / 2 <= blk) ++a;
+      const uint32_t bb = blk - a * (a + 1) / 2, dd = a - bb;
+      const double v = Spp[i];
+      if (dd <= d.bw && v != 0.0 && !(dd == 0 && (e % 6) > (e / 6))) atomicAdd(d.Sband + ((size_t)(flo + a) * (d.bw + 1) + dd) * 36 + e, v);
+    }
+    for (uint32_t i = tid; i < (uint32_t)NC * 6 * nf; i += 256) {
+      const uint32_t j = i / (6 * nf), cidx = i % (6 * nf);
+      atomicAdd(d.Sarrow + (size_t)(camrow + j) * d.ld + 6 * flo + cidx, Scp[(size_t)j * 6 * NFm + cidx]);
+    }
+    if (tid < (uint32_t)NCC) {
+      uint32_t i = 0; while ((i + 1) * (i + 2) / 2 <= tid) ++i;
+      const uint32_t j = tid - i * (i + 1) / 2;
+      atomicAdd(d.Sarrow + (size_t)(camrow + i) * d.ld + camcol + j, Scc[tid]);
+    }
+    for (uint32_t i = tid; i < 6 * nf; i += 256) { atomicAdd(d.gB + 6 * flo + i, vgB[i]); atomicAdd(d.rhsacc + 6 * flo + i, vrhs[i]); }
+    if (tid < (uint32_t)NC) { atomicAdd(d.gB + camcol + tid, vgB[6 * NFm + tid]); atomicAdd(d.rhsacc + camcol + tid, vrhs[6 * NFm + tid]); }
+    if (tid == 0) {
+      atomicAdd(d.scal + SCAL_COST, misc[0]);
+      if (misc[1] != 0.0) atomicAdd(d.scal + SCAL_BAD_U, misc[1]);
+      atomicMax((unsigned long long*)(d.scal + SCAL_GMAX0 + d.rank), *(unsigned long long*)(misc + 2));
+    }
+  }
+#ifdef LIFCAL_STAMPS
+  __syncthreads();
+  STAMP(6);
+  if (tid == 0 && d.dbg) for (int i = 0; i < 8; ++i) d.dbg[(size_t)b * 8 + i] = st_acc[i];
+#endif
+}
+
+}  // namespace lifcal
