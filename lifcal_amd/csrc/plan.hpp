@@ -277,7 +277,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
       L.max_block_nf = std::max(L.max_block_nf, fhi - flo + 1);
       // passes inside the block; the dense Z matrix of a pass (3 np rows x padded window columns) must fit its LDS budget
       const uint32_t ncolp = ((6 * (fhi - flo + 1) + (uint32_t)L.nc + 1) + 15u) & ~15u;
-      const uint32_t np_cap = std::max(1u, std::min<uint32_t>(Plan::NP_MAX, ((Plan::ZD_DOUBLES / ncolp) & ~3u) / 3));
+      const uint32_t np_cap = std::max(1u, std::min<uint32_t>(Plan::NP_MAX, ((Plan::ZD_DOUBLES / (ncolp + 2)) & ~3u) / 3));
       size_t a = i;
       while (a < j) {
         uint32_t ng = 0, np = 0; size_t e = a;

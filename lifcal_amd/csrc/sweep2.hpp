@@ -10,8 +10,9 @@
 //       LDS f64 atomics; W_pose goes straight to HBM (back-substitution) and into its cell of Zd,
 //   (2) one thread per point damps and factors U = L L^T (ceres LevenbergMarquardtStrategy + InvertPSDMatrix<3>),
 //   (3) Zd <- L^-1 W row-wise; rhs column = L^-1 g,
-//   (4) window -= Zd^T Zd on the f64 matrix cores (v_mfma_f64_16x16x4_f64): every 16x16 output tile is owned by one
-//       wave, so the point elimination W^T U^-1 W (and W^T U^-1 g, the last column) needs no atomics at all.
+//   (4) window -= Zd^T Zd as a register-blocked fp64 product (4x4 micro-tiles per lane; on gfx950 v_fmac_f64 beats
+//       v_mfma_f64_16x16x4_f64, measured in tools/ubench): every output entry has one owner, so the point elimination
+//       W^T U^-1 W (and W^T U^-1 g, the last column) needs no atomics at all.
 // mode 1 ("diagonal only", iteration 0): just the Hessian diagonal for the Jacobi scaling.
 // Replaces, per LM iteration: ceres autodiff evaluation of OurCostFunctionBundle (reference
 // src/BundleAdjustment/BundleAdjustment.h:120-222) + SchurEliminator::Eliminate (out of tree).
@@ -83,7 +84,8 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   const uint32_t b = blockIdx.x;
   const uint32_t flo = d.blk_flo[b], nf = d.blk_nf[b];
-  const uint32_t ncol = 6 * nf + NC + 1, ncolp = (ncol + 15u) & ~15u;   // pose | camera | rhs, padded to MFMA tiles
+  const uint32_t ncol = 6 * nf + NC + 1, ncolp = (ncol + 15u) & ~15u;   // pose | camera | rhs, padded
+  const uint32_t zs = ncolp + 2;   // row stride of Zd: ncolp is a multiple of 16 doubles (= all rows on one LDS bank), +2 spreads the rows
   const CamConsts c = *d.camc;
 #ifdef LIFCAL_STAMPS
   unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     const uint32_t np = d.pass_np[ps], pt0 = d.pass_pt0[ps], gid0 = d.pass_gid0[ps];
     const uint32_t krows = (3 * np + 3u) & ~3u;   // K of the product, multiple of 4
     for (uint32_t i = tid; i < 64 * 12; i += 256) slab[i] = 0.0;
-    if (mode == 0) for (uint32_t i = tid; i < krows * ncolp; i += 256) Zd[i] = 0.0;
+    if (mode == 0) for (uint32_t i = tid; i < krows * zs; i += 256) Zd[i] = 0.0;
     __syncthreads();
     STAMP(0);
     // ---------------- phase 1: observations -> LDS blocks ----------------
@@ -192,7 +194,9 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #pragma unroll
           for (int j = 0; j < 3; ++j) GAG[i][j] = Gr[0][i] * AG[0][j] + Gr[1][i] * AG[1][j] + Gr[2][i] * AG[2][j];
         // frame-level values go to this lane's replica, value-major: every lane of the wave instruction hits its own address
-        double* fr_acc = Fr + (size_t)rep * FRV * NFm + lf;
+        // slot = frame * R + replica: consecutive doubles across the lanes of one instruction (bank-ideal, no address clash)
+        const uint32_t frs = NFm * lay.nrep;
+        double* fr_acc = Fr + (size_t)lf * lay.nrep + rep;
         {
           int vi = 0;
 #pragma unroll
@@ -201,20 +205,20 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
             for (int bb = 0; bb <= a; ++bb) {
               double v;
               if (a < 3) v = GAG[a][bb]; else if (bb < 3) v = AG[a - 3][bb]; else v = Am[a - 3][bb - 3];
-              atomicAdd(fr_acc + (size_t)vi * NFm, v);
+              atomicAdd(fr_acc + (size_t)vi * frs, v);
               ++vi;
             }
 #pragma unroll
-          for (int a = 0; a < 3; ++a) atomicAdd(fr_acc + (size_t)(21 + a) * NFm, Gr[0][a] * bv[0] + Gr[1][a] * bv[1] + Gr[2][a] * bv[2]);
+          for (int a = 0; a < 3; ++a) atomicAdd(fr_acc + (size_t)(21 + a) * frs, Gr[0][a] * bv[0] + Gr[1][a] * bv[1] + Gr[2][a] * bv[2]);
 #pragma unroll
-          for (int a = 0; a < 3; ++a) atomicAdd(fr_acc + (size_t)(24 + a) * NFm, bv[a]);
+          for (int a = 0; a < 3; ++a) atomicAdd(fr_acc + (size_t)(24 + a) * frs, bv[a]);
           if (mode == 0) {
 #pragma unroll
             for (int j = 0; j < NC; ++j) {
 #pragma unroll
-              for (int ci = 0; ci < 3; ++ci) atomicAdd(fr_acc + (size_t)(27 + j * 6 + ci) * NFm, C[0][j] * Gr[0][ci] + C[1][j] * Gr[1][ci] + C[2][j] * Gr[2][ci]);
+              for (int ci = 0; ci < 3; ++ci) atomicAdd(fr_acc + (size_t)(27 + j * 6 + ci) * frs, C[0][j] * Gr[0][ci] + C[1][j] * Gr[1][ci] + C[2][j] * Gr[2][ci]);
 #pragma unroll
-              for (int ci = 0; ci < 3; ++ci) atomicAdd(fr_acc + (size_t)(27 + j * 6 + 3 + ci) * NFm, C[ci][j]);
+              for (int ci = 0; ci < 3; ++ci) atomicAdd(fr_acc + (size_t)(27 + j * 6 + 3 + ci) * frs, C[ci][j]);
             }
           }
         }
@@ -238,7 +242,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             atomicAdd(acc + 6 + i, R[i] * bv[0] + R[3 + i] * bv[1] + R[6 + i] * bv[2]);
-            double* zrow = Zd + (size_t)(3 * lp + i) * ncolp;
+            double* zrow = Zd + (size_t)(3 * lp + i) * zs;
 #pragma unroll
             for (int j = 0; j < NC; ++j) atomicAdd(zrow + 6 * nf + j, R[i] * C[0][j] + R[3 + i] * C[1][j] + R[6 + i] * C[2][j]);
 #pragma unroll
@@ -249,6 +253,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
         }
       }
     }
+    STAMP(6);
     __syncthreads();
     STAMP(1);
     // ---------------- phase 2: one thread per point: damp, factor U = L L^T ----------------
@@ -288,8 +293,8 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
         atomicMax((unsigned long long*)(misc + 2), (unsigned long long)__double_as_longlong(gm));
         acc[0] = i00; acc[1] = m10; acc[2] = m20; acc[3] = i11; acc[4] = m21; acc[5] = i22;
         // rhs column of Zd: L^-1 g
-        double* z0 = Zd + (size_t)(3 * tid) * ncolp + (ncol - 1);
-        z0[0] = i00 * g0; z0[ncolp] = m10 * g0 + i11 * g1; z0[2 * ncolp] = m20 * g0 + m21 * g1 + i22 * g2;
+        double* z0 = Zd + (size_t)(3 * tid) * zs + (ncol - 1);
+        z0[0] = i00 * g0; z0[zs] = m10 * g0 + i11 * g1; z0[2 * zs] = m20 * g0 + m21 * g1 + i22 * g2;
       }
     }
     __syncthreads();
@@ -300,53 +305,62 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
       for (uint32_t t = tid; t < np * nwc; t += 256) {
         const uint32_t lp = t / nwc, cidx = t % nwc;
         const double* acc = slab + lp * 12;
-        double* z = Zd + (size_t)(3 * lp) * ncolp + cidx;
-        const double w0 = z[0], w1 = z[ncolp], w2 = z[2 * ncolp];
+        double* z = Zd + (size_t)(3 * lp) * zs + cidx;
+        const double w0 = z[0], w1 = z[zs], w2 = z[2 * zs];
         if (cidx >= 6 * nf) {
           double* ga = d.ptacc + (size_t)d.v2_points[pt0 + lp] * 36 + 9 + (cidx - 6 * nf);
           ga[0] = w0; ga[NCMAX] = w1; ga[2 * NCMAX] = w2;
         }
-        z[0] = acc[0] * w0; z[ncolp] = acc[1] * w0 + acc[3] * w1; z[2 * ncolp] = acc[2] * w0 + acc[4] * w1 + acc[5] * w2;
+        z[0] = acc[0] * w0; z[zs] = acc[1] * w0 + acc[3] * w1; z[2 * zs] = acc[2] * w0 + acc[4] * w1 + acc[5] * w2;
       }
       __syncthreads();
       STAMP(3);
       // ---------------- phase 4: window -= Zd^T Zd on the f64 matrix cores, one 16x16 output tile per wave at a time ----------------
-      const uint32_t ntile = ncolp >> 4;
-      const uint32_t ntri = ntile * (ntile + 1) / 2;
-      const uint32_t li = lane & 15u, lk = lane >> 4;
-      constexpr int NT = 6;   // independent accumulator tiles per wave: hides the MFMA accumulate latency and the LDS reads
-      for (uint32_t t0 = w; t0 < ntri; t0 += 4 * NT) {
-        uint32_t tis[NT], tjs[NT];
-        const double* za[NT]; const double* zb[NT];
-        v4f64 accm[NT];
+      // Register-blocked fp64 product on the vector ALUs: measured on gfx950, v_fmac_f64 (6.3 cycles per wave
+      // instruction, 64 MAC) outruns v_mfma_f64_16x16x4_f64 (~140 cycles, 1024 MAC) by ~1.4x, so the product
+      // runs as 4x4 micro-tiles per lane over the lower triangle; each output entry has exactly one owner.
+      const uint32_t nmt = (ncol + 3u) >> 2;               // micro-tile rows/cols that contain real columns
+      const uint32_t ntri = nmt * (nmt + 1) / 2;
+      for (uint32_t t = tid; t < ntri; t += 256) {
+        uint32_t mi = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (mi * (mi + 1) / 2 > t) --mi;
+        while ((mi + 1) * (mi + 2) / 2 <= t) ++mi;
+        const uint32_t mj = t - mi * (mi + 1) / 2;
+        double acc16[4][4];
 #pragma unroll
-        for (int q = 0; q < NT; ++q) {
-          uint32_t t = t0 + 4 * q; if (t >= ntri) t = t0;   // surplus slots recompute tile t0 and are not written back
-          uint32_t ti = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-          while (ti * (ti + 1) / 2 > t) --ti;
-          while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
-          tis[q] = ti; tjs[q] = t - ti * (ti + 1) / 2;
-          // A operand: lane holds A[i = lane&15][k = lane>>4] = Zd[k0 + k][16 ti + i]; B operand: Zd[k0 + k][16 tj + j]
-          za[q] = Zd + (size_t)lk * ncolp + tis[q] * 16 + li;
-          zb[q] = Zd + (size_t)lk * ncolp + tjs[q] * 16 + li;
-          accm[q] = v4f64{0.0, 0.0, 0.0, 0.0};
-        }
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc16[i][j] = 0.0;
+        const double* za = Zd + 4 * mi;
+        const double* zb = Zd + 4 * mj;
+        // four rows of Zd per step: 16 ds_read_b128 in flight, then 64 FMAs (one wave per SIMD: the only way to amortise
+        // the LDS latency); rows beyond 3 np are zero because krows is rounded up to 4 and the pass zero-fills them
         for (uint32_t k0 = 0; k0 < krows; k0 += 4) {
-          double av[NT], bvv[NT];
-#pragma unroll
-          for (int q = 0; q < NT; ++q) { av[q] = za[q][(size_t)k0 * ncolp]; bvv[q] = zb[q][(size_t)k0 * ncolp]; }
-#pragma unroll
-          for (int q = 0; q < NT; ++q) accm[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bvv[q], accm[q], 0, 0, 0);
-        }
-        // f64 C/D layout: D[row = (lane>>4) + 4 r][col = lane&15]; row indexes the ti tile, col the tj tile
-#pragma unroll
-        for (int q = 0; q < NT; ++q) {
-          if (t0 + 4 * q >= ntri) continue;
-          const uint32_t cj = tjs[q] * 16 + li;
+          double2 aq[4][2], bq2[4][2];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const uint32_t ci = tis[q] * 16 + lk + 4 * r;
-            const double dv = accm[q][r];
+            aq[r][0] = *reinterpret_cast<const double2*>(za + (size_t)(k0 + r) * zs);
+            aq[r][1] = *reinterpret_cast<const double2*>(za + (size_t)(k0 + r) * zs + 2);
+            bq2[r][0] = *reinterpret_cast<const double2*>(zb + (size_t)(k0 + r) * zs);
+            bq2[r][1] = *reinterpret_cast<const double2*>(zb + (size_t)(k0 + r) * zs + 2);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const double av[4] = {aq[r][0].x, aq[r][0].y, aq[r][1].x, aq[r][1].y};
+            const double bq[4] = {bq2[r][0].x, bq2[r][0].y, bq2[r][1].x, bq2[r][1].y};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) acc16[i][j] += av[i] * bq[j];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const uint32_t ci = 4 * mi + i;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t cj = 4 * mj + j;
+            const double dv = acc16[i][j];
             if (ci >= ncol || cj >= ncol || ci < cj) continue;
             if (ci < 6 * nf) {            // pose x pose
               const uint32_t lfi = ci / 6, lfj = cj / 6;
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
   for (uint32_t i = tid; i < FRV * nf; i += 256) {
     const uint32_t v = i / nf, lf = i % nf;
     double sacc = 0.0;
-    for (uint32_t r = 0; r < lay.nrep; ++r) sacc += Fr[((size_t)r * FRV + v) * NFm + lf];
+    for (uint32_t r = 0; r < lay.nrep; ++r) sacc += Fr[(size_t)v * NFm * lay.nrep + lf * lay.nrep + r];
     if (v < 21) {
       uint32_t a = 0; while ((a + 1) * (a + 2) / 2 <= v) ++a;
       const uint32_t bb = v - a * (a + 1) / 2;
@@ -436,7 +450,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
   }
 #ifdef LIFCAL_STAMPS
   __syncthreads();
-  STAMP(6);
+  STAMP(5);
   if (tid == 0 && d.dbg) for (int i = 0; i < 8; ++i) d.dbg[(size_t)b * 8 + i] = st_acc[i];
 #endif
 }
