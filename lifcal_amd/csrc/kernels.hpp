@@ -123,6 +123,38 @@ __global__ void k_lenses(const CamConsts* camc, const double* lens_xy, double* l
   for (int k = 0; k < LENS_STRIDE; ++k) lt[(size_t)l * LENS_STRIDE + k] = o[k];
 }
 
+// one launch for everything that precedes a sweep: camera constants (recomputed by every thread: ~100 flops, no
+// dependency on another kernel), lens table, frame table, and zero-filling of the accumulation buffers
+template <int NR, bool TAN>
+__global__ __launch_bounds__(256) void k_tables(Dev d, const double* cam, const double* views, CamConsts* camc_out, double* ft, double* lt,
+                                                const double* lens_xy, int want_tangents, int fold, double* zero0, uint32_t n_zero0, double* zero1, uint32_t n_zero1) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+  CamConsts c;
+  cam_prepare(cam, d.spx, d.spy, fold ? d.scale : (double)(float)d.scale, (int)d.n_radial, d.tangential != 0, d.fixed_mask, d.loss_scale, fold != 0, c);
+  if (t == 0) *camc_out = c;
+  if (t < d.n_lenses) {
+    double o[LENS_STRIDE];
+#pragma unroll
+    for (int k = 0; k < LENS_STRIDE; ++k) o[k] = 0.0;
+    lens_eval<NR, TAN>(c, lens_xy[2 * (size_t)t], lens_xy[2 * (size_t)t + 1], want_tangents != 0, o);
+#pragma unroll
+    for (int k = 0; k < LENS_STRIDE; ++k) lt[(size_t)t * LENS_STRIDE + k] = o[k];
+  }
+  if (t < d.F) {
+    double o[FRAME_STRIDE]; frame_eval(views + 6 * (size_t)t, o);
+#pragma unroll
+    for (int k = 0; k < FRAME_STRIDE; ++k) ft[(size_t)t * FRAME_STRIDE + k] = o[k];
+  }
+  for (uint32_t i = t; i < n_zero0; i += nthreads) zero0[i] = 0.0;
+  for (uint32_t i = t; i < n_zero1; i += nthreads) zero1[i] = 0.0;
+}
+
+// point slabs of the special points (the v1 kernels accumulate into them with atomics)
+__global__ void k_zero_special(Dev d) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < d.n_special * 36) d.ptacc[(size_t)d.special_owned[t / 36] * 36 + t % 36] = 0.0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // sweep: one lane per (point, frame) group
 // ---------------------------------------------------------------------------------------------
@@ -675,9 +707,10 @@ __global__ __launch_bounds__(1024) void k_band_backsolve(Dev d) {
 // step application
 // ---------------------------------------------------------------------------------------------
 // camera + poses + promoted points: candidate = Plus(x, delta) with box projection (ceres ParameterBlock::Plus)
-__global__ void k_update_reduced(Dev d) {
+__global__ void k_update_reduced(Dev d, double* partial) {
   __shared__ double red[4];
   if (threadIdx.x < 4) red[threadIdx.x] = 0.0;
+  if (threadIdx.x < 8) partial[threadIdx.x] = 0.0;   // scalars of the candidate step (k_backsub / k_cost accumulate into them next)
   __syncthreads();
   const uint32_t F6 = 6 * d.F, camcol = F6 + 3 * d.Q;
   double gtd = 0.0, ddd = 0.0, st2 = 0.0, x2 = 0.0;

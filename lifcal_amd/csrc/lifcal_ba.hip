@@ -154,26 +154,24 @@ uint32_t sweep_grid(const lifcal_ba_handle* h) {
   return std::max(1u, std::min(wgs, 2048u));
 }
 
-// tables for a parameter set: camera constants, frames, lenses
-int launch_tables(lifcal_ba_handle* h, const double* cam, const double* views, CamConsts* camc, double* ft, double* lt, bool tangents, bool fold) {
+// tables for a parameter set (camera constants, frames, lenses) + zero-fill of up to two buffers, ONE launch
+int launch_tables(lifcal_ba_handle* h, const double* cam, const double* views, CamConsts* camc, double* ft, double* lt, bool tangents, bool fold,
+                  double* zero0 = nullptr, size_t n_zero0 = 0, double* zero1 = nullptr, size_t n_zero1 = 0) {
   const Dev& d = h->d;
-  hipLaunchKernelGGL(k_camc, dim3(1), dim3(64), 0, h->stream, cam, camc, d.spx, d.spy, d.scale, (int)d.n_radial, (int)d.tangential,
-                     d.fixed_mask, d.loss_scale, fold ? 1 : 0);
-  if (d.F) hipLaunchKernelGGL(k_frames, dim3((d.F + 255) / 256), dim3(256), 0, h->stream, views, ft, d.F);
-  if (d.n_lenses) {
-#define CALL_LENS(NR, TAN) hipLaunchKernelGGL((k_lenses<NR, TAN>), dim3((d.n_lenses + 255) / 256), dim3(256), 0, h->stream, camc, h->lens_xy, lt, d.n_lenses, tangents ? 1 : 0)
-    DISPATCH_LENS(h, CALL_LENS);
-#undef CALL_LENS
-  }
+  const uint32_t work = std::max<uint32_t>(std::max(d.n_lenses, d.F), (uint32_t)std::min<size_t>((n_zero0 + n_zero1 + 7) / 8, 1u << 20));
+  const uint32_t grid = std::max(1u, (work + 255) / 256);
+#define CALL_TABLES(NR, TAN) hipLaunchKernelGGL((k_tables<NR, TAN>), dim3(grid), dim3(256), 0, h->stream, d, cam, views, camc, ft, lt, (const double*)h->lens_xy, tangents ? 1 : 0, fold ? 1 : 0, zero0, (uint32_t)n_zero0, zero1, (uint32_t)n_zero1)
+  DISPATCH_LENS(h, CALL_TABLES);
+#undef CALL_TABLES
   HIP_TRY(hipGetLastError());
   return 0;
 }
 
 // the kernels that turn observations into blocks.  mode 1 = Hessian diagonal only (Jacobi scaling, iteration 0)
-int launch_blocks(lifcal_ba_handle* h, double radius, int mode) {
+int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
   Dev& d = h->d;
-  HIP_TRY(hipMemsetAsync(h->red_block, 0, h->red_count * sizeof(double), h->stream));
-  HIP_TRY(hipMemsetAsync(d.ptacc, 0, (size_t)d.P * 36 * sizeof(double), h->stream));
+  if (!zeroed) HIP_TRY(hipMemsetAsync(h->red_block, 0, h->red_count * sizeof(double), h->stream));
+  if (d.n_special) hipLaunchKernelGGL(k_zero_special, dim3((d.n_special * 36 + 255) / 256), dim3(256), 0, h->stream, d);
   if (mode == 0 && h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(1), h->stream));
   if (d.n_blocks) {   // regular points: LDS-window kernel, one workgroup per block
 #define CALL_SWEEP2(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep2<NR, TAN, ADJ>), dim3(d.n_blocks), dim3(256), h->v2_lds_bytes, h->stream, d, radius, mode)
@@ -195,12 +193,15 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode) {
 // one Jacobian + Schur sweep at the current point and the given trust-region radius
 int launch_sweep(lifcal_ba_handle* h, double radius) {
   Dev& d = h->d;
-  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));
-  if (int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true)) return rc;
+  if (h->prof_active() && h->prof_used == 0) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));
+  // the table kernel also zero-fills the reduced block and the step scalars
+  if (int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true, h->red_block, h->red_count, d.step, ST_N)) return rc;
+  bool zeroed = true;
   if (!h->sigma_valid) {
     // ceres fixes the Jacobi scaling at iteration 0 from the column norms of the (loss-corrected) Jacobian:
     // a diagonal-only pass, then 1 / (1 + sqrt(diag)) for every column
-    if (int rc = launch_blocks(h, radius, 1)) return rc;
+    if (int rc = launch_blocks(h, radius, 1, zeroed)) return rc;
+    zeroed = false;
     const double* hd = d.hdiag;
     if (h->opt.world_size > 1) {
       HIP_TRY(hipMemcpyAsync(h->hdiag_tmp, d.hdiag, d.n_red * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
@@ -213,16 +214,13 @@ int launch_sweep(lifcal_ba_handle* h, double radius) {
     HIP_TRY(hipGetLastError());
     h->sigma_valid = true;
   }
-  if (int rc = launch_blocks(h, radius, 0)) return rc;
-  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(3), h->stream));
+  if (int rc = launch_blocks(h, radius, 0, zeroed)) return rc;
   if (d.use_points && d.n_special) hipLaunchKernelGGL(k_schur, dim3((d.n_special + 3) / 4), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
-  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(4), h->stream));
   if (int rc = do_allreduce(h, h->red_block, h->red_count)) return rc;
-  HIP_TRY(hipMemsetAsync(d.step, 0, ST_N * sizeof(double), h->stream));
   hipLaunchKernelGGL(k_finalize, dim3((d.n_red + 255) / 256), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
-  if (h->prof_active()) { HIP_TRY(hipEventRecord(h->prof_ev(5), h->stream)); h->prof_used++; }
+  if (h->prof_active()) { HIP_TRY(hipEventRecord(h->prof_ev(5), h->stream)); h->prof_used++; }   // event 5 of the LAST sweep closes the timed span
   return 0;
 }
 
@@ -252,8 +250,7 @@ int launch_linear_solve(lifcal_ba_handle* h) {
 // candidate point x + delta, its cost and the scalars of the step-quality test
 int launch_candidate(lifcal_ba_handle* h) {
   Dev& d = h->d;
-  HIP_TRY(hipMemsetAsync(h->partial, 0, 8 * sizeof(double), h->stream));
-  hipLaunchKernelGGL(k_update_reduced, dim3(1), dim3(256), 0, h->stream, d);
+  hipLaunchKernelGGL(k_update_reduced, dim3(1), dim3(256), 0, h->stream, d, h->partial);
   const uint32_t n = std::max(d.n_owned, d.Q);
   if (d.use_points && n) hipLaunchKernelGGL(k_backsub, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, h->partial);
   HIP_TRY(hipGetLastError());
@@ -452,7 +449,8 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   { int32_t* t; U(t, L.promoted); d.promoted = t; }
   { uint32_t* t; U(t, L.promoted_ids); d.promoted_ids = t; U(t, L.pt_slot0); d.pt_slot0 = t; U(t, L.pt_nslots); d.pt_nslots = t; U(t, L.owned_points); d.owned = t; }
   { std::vector<uint8_t> live(L.frame_used); uint8_t* t; U(t, live); d.frame_live = t; }
-  A(d.ptacc, (size_t)d.P * 36); A(d.Uinv, (size_t)d.P * 9); A(d.lamP, (size_t)d.P * 3); A(d.sigP, (size_t)d.P * 3);
+  A(d.ptacc, (size_t)d.P * 36); A(d.Uinv, (size_t)d.P * 9);
+  if (hipMemset(d.ptacc, 0, (size_t)std::max(1u, d.P) * 36 * sizeof(double)) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); A(d.lamP, (size_t)d.P * 3); A(d.sigP, (size_t)d.P * 3);
   A(d.Wv, (size_t)L.n_groups * 18);
   if (L.use_constraints) {
     uint32_t* t; U(t, L.c_i); d.c_i = t; U(t, L.c_j); d.c_j = t; U(t, L.my_constraints); d.my_cons = t;
@@ -560,14 +558,18 @@ int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::memset(out, 0, sizeof(*out));
   const uint32_t n = h->prof_used;
-  for (uint32_t i = 0; i < n; ++i) {
-    float a = 0, b = 0, c = 0, t = 0;
+  for (uint32_t i = 0; i < n; ++i) {   // per sweep: events 1 / 2 bracket the dominant kernel(s) (k_sweep2 [+ k_sweep])
+    float bms = 0;
     hipEvent_t* e = &h->prof_events[(size_t)i * 6];
-    HIP_TRY(hipEventElapsedTime(&a, e[0], e[1])); HIP_TRY(hipEventElapsedTime(&b, e[1], e[2]));
-    HIP_TRY(hipEventElapsedTime(&c, e[3], e[4])); HIP_TRY(hipEventElapsedTime(&t, e[0], e[5]));
-    out->ms_tables += a; out->ms_accumulate += b; out->ms_schur += c; out->ms_total += t;
+    HIP_TRY(hipEventElapsedTime(&bms, e[1], e[2]));
+    out->ms_accumulate += bms;
   }
-  if (n) { out->ms_tables /= n; out->ms_accumulate /= n; out->ms_schur /= n; out->ms_total /= n; }
+  if (n) {
+    float t = 0;   // first kernel of the first sweep -> end of the last sweep
+    HIP_TRY(hipEventElapsedTime(&t, h->prof_events[0], h->prof_events[(size_t)(n - 1) * 6 + 5]));
+    out->ms_total = t / n; out->ms_accumulate /= n;
+    out->ms_tables = 0.0; out->ms_schur = 0.0;
+  }
   out->n_sweeps = n;
   h->prof_on = false;
   return 0;

@@ -34,11 +34,11 @@ struct V2Lds {
     off_fr = off_vec + 3 * (6 * nfm + NCMAX + 3);
     off_fr = (off_fr + 1) & ~1u;
     // replicated frame accumulators [rep][value][frame]: as many replicas (<= 8) as the 160 KiB LDS allows
-    const uint32_t fixed = off_fr + 64 * 12 + ZD_DOUBLES + 8;
+    const uint32_t fixed = off_fr + 64 * 12 + ZD_DOUBLES + 8 + 32 + 64;
     uint32_t r = (LDS_LIMIT_DOUBLES - fixed) / (FRV * nfm);
     nrep = r < 1 ? 1 : (r > 8 ? 8 : r);
     off_slab = off_fr + nrep * FRV * nfm;
-    off_zd = off_slab + 64 * 12; off_misc = off_zd + ZD_DOUBLES; total = off_misc + 8;
+    off_zd = off_slab + 64 * 12; off_misc = off_zd + ZD_DOUBLES; total = off_misc + 8 + 32 + 64;   // misc(8) | point ids (64 u32) | column info (<= 256 u16)
   }
 };
 
@@ -81,6 +81,8 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
   double* slab = sm + lay.off_slab;   // per point of the pass: [0..5] U -> L^-1, [6..8] g
   double* Zd = sm + lay.off_zd;
   double* misc = sm + lay.off_misc;   // [0] cost, [1] bad-U count, [2] max |g_p| (as bits)
+  uint32_t* pidl = (uint32_t*)(misc + 8);                 // global id of each point of the pass
+  unsigned short* colinfo = (unsigned short*)(misc + 8 + 32);   // per window column: pose (lf<<8 | comp), camera 0x8000|j, rhs 0xC000
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   const uint32_t b = blockIdx.x;
   const uint32_t flo = d.blk_flo[b], nf = d.blk_nf[b];
@@ -93,6 +95,8 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #endif
   for (uint32_t i = tid; i < lay.off_slab; i += 256) sm[i] = 0.0;
   if (tid < 8) misc[tid] = 0.0;
+  for (uint32_t cI = tid; cI < ncolp; cI += 256)
+    colinfo[cI] = (cI < 6 * nf) ? (unsigned short)(((cI / 6) << 8) | (cI % 6)) : (cI < ncol - 1 ? (unsigned short)(0x8000u | (cI - 6 * nf)) : (unsigned short)0xC000u);
   double cc[NCC], gc[NC], cost = 0.0;
 #pragma unroll
   for (int i = 0; i < NCC; ++i) cc[i] = 0.0;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     const uint32_t np = d.pass_np[ps], pt0 = d.pass_pt0[ps], gid0 = d.pass_gid0[ps];
     const uint32_t krows = (3 * np + 3u) & ~3u;   // K of the product, multiple of 4
     for (uint32_t i = tid; i < 64 * 12; i += 256) slab[i] = 0.0;
-    if (mode == 0) for (uint32_t i = tid; i < krows * zs; i += 256) Zd[i] = 0.0;
+    if (mode == 0) { double2* z2 = reinterpret_cast<double2*>(Zd); for (uint32_t i = tid; i < (krows * zs) / 2; i += 256) z2[i] = double2{0.0, 0.0}; }
     __syncthreads();
     STAMP(0);
     // ---------------- phase 1: observations -> LDS blocks ----------------
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < NC; ++j) C[i][j] = 0.0;
+      // (a 3-stage software prefetch of the next observations was measured: no gain, the loop is issue-bound)
       for (uint32_t k = 0; k < kmax; ++k) {
         if (k < cnt) {
           const size_t at = ((size_t)row0 + k) * 64 + lane;
@@ -259,6 +264,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     // ---------------- phase 2: one thread per point: damp, factor U = L L^T ----------------
     if (tid < np) {
       const uint32_t p = d.v2_points[pt0 + tid];
+      pidl[tid] = p;
       double* acc = slab + tid * 12;
       double U0 = acc[0], U1 = acc[1], U2 = acc[2], U3 = acc[3], U4 = acc[4], U5 = acc[5];
       if (mode == 1) {
@@ -301,17 +307,23 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     STAMP(2);
     if (mode == 0) {
       // ---------------- phase 3: camera part of W -> HBM, then Z = L^-1 W in place (pose + camera columns) ----------------
+      // thread = (column, point-phase): no per-item div/mod, point ids come from LDS
       const uint32_t nwc = ncol - 1;
-      for (uint32_t t = tid; t < np * nwc; t += 256) {
-        const uint32_t lp = t / nwc, cidx = t % nwc;
-        const double* acc = slab + lp * 12;
-        double* z = Zd + (size_t)(3 * lp) * zs + cidx;
-        const double w0 = z[0], w1 = z[zs], w2 = z[2 * zs];
-        if (cidx >= 6 * nf) {
-          double* ga = d.ptacc + (size_t)d.v2_points[pt0 + lp] * 36 + 9 + (cidx - 6 * nf);
-          ga[0] = w0; ga[NCMAX] = w1; ga[2 * NCMAX] = w2;
+      const uint32_t nth = 256 / nwc > 0 ? 256 / nwc : 1;
+      const uint32_t gi = tid / nwc, cidx = tid - gi * nwc;
+      if (gi < nth || nwc > 256) {
+        for (uint32_t cc0 = cidx; cc0 < nwc; cc0 += (nwc > 256 ? 256 : nwc * nth)) {
+          for (uint32_t lp = (nwc > 256 ? 0 : gi); lp < np; lp += (nwc > 256 ? 1 : nth)) {
+            const double* acc = slab + lp * 12;
+            double* z = Zd + (size_t)(3 * lp) * zs + cc0;
+            const double w0 = z[0], w1 = z[zs], w2 = z[2 * zs];
+            if (cc0 >= 6 * nf) {
+              double* ga = d.ptacc + (size_t)pidl[lp] * 36 + 9 + (cc0 - 6 * nf);
+              ga[0] = w0; ga[NCMAX] = w1; ga[2 * NCMAX] = w2;
+            }
+            z[0] = acc[0] * w0; z[zs] = acc[1] * w0 + acc[3] * w1; z[2 * zs] = acc[2] * w0 + acc[4] * w1 + acc[5] * w2;
+          }
         }
-        z[0] = acc[0] * w0; z[zs] = acc[1] * w0 + acc[3] * w1; z[2 * zs] = acc[2] * w0 + acc[4] * w1 + acc[5] * w2;
       }
       __syncthreads();
       STAMP(3);
@@ -357,20 +369,22 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const uint32_t ci = 4 * mi + i;
+          const uint32_t ii = colinfo[ci < ncolp ? ci : 0];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const uint32_t cj = 4 * mj + j;
             const double dv = acc16[i][j];
             if (ci >= ncol || cj >= ncol || ci < cj) continue;
-            if (ci < 6 * nf) {            // pose x pose
-              const uint32_t lfi = ci / 6, lfj = cj / 6;
-              Spp[(size_t)(lfi * (lfi + 1) / 2 + lfj) * 36 + (ci % 6) * 6 + (cj % 6)] -= dv;
-            } else if (ci < ncol - 1) {   // camera row
-              const uint32_t jc = ci - 6 * nf;
-              if (cj < 6 * nf) Scp[(size_t)jc * 6 * NFm + cj] -= dv;
-              else Scc[jc * (jc + 1) / 2 + (cj - 6 * nf)] -= dv;
-            } else if (cj < ncol - 1) {   // rhs row: W^T U^-1 g
-              if (cj < 6 * nf) vrhs[cj] += dv; else vrhs[6 * NFm + (cj - 6 * nf)] += dv;
+            const uint32_t jj = colinfo[cj];
+            if (!(ii & 0x8000u)) {            // pose x pose
+              const uint32_t lfi = ii >> 8, lfj = jj >> 8;
+              Spp[(size_t)(lfi * (lfi + 1) / 2 + lfj) * 36 + (ii & 0xFFu) * 6 + (jj & 0xFFu)] -= dv;
+            } else if (!(ii & 0x4000u)) {     // camera row
+              const uint32_t jc = ii & 0xFFu;
+              if (!(jj & 0x8000u)) Scp[(size_t)jc * 6 * NFm + cj] -= dv;
+              else Scc[jc * (jc + 1) / 2 + (jj & 0xFFu)] -= dv;
+            } else if (cj < ncol - 1) {       // rhs row: W^T U^-1 g
+              if (!(jj & 0x8000u)) vrhs[cj] += dv; else vrhs[6 * NFm + (jj & 0xFFu)] += dv;
             }
           }
         }
@@ -379,22 +393,36 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     __syncthreads();
     STAMP(4);
   }
-  // ---------------- camera x camera block, camera gradient, cost: DPP wave reduction into LDS ----------------
+  // ---------------- camera x camera block, camera gradient, cost: 256-way reduction through LDS ----------------
+  // every thread parks its partial sums as [value][thread] in the (now free) Zd region, 8 threads per value add them up
   {
-    int t = 0;
+    constexpr int NV = NCC + NC + 1, RV = 28;   // 28 values x 256 threads x 8 B = 56 KiB per round
 #pragma unroll
-    for (int i = 0; i < NC; ++i) {
+    for (int round = 0; round * RV < NV; ++round) {
 #pragma unroll
-      for (int j = 0; j <= i; ++j) {
-        const double s = wave_sum_dpp(cc[t]);
-        if (lane == 63) { if (mode == 0) atomicAdd(Scc + i * (i + 1) / 2 + j, s); if (i == j) atomicAdd(vhd + 6 * NFm + i, s); }
-        ++t;
+      for (int v = 0; v < RV; ++v) {
+        const int idx = round * RV + v;
+        if (idx < NV) Zd[v * 256 + tid] = (idx < NCC) ? cc[idx < NCC ? idx : 0] : (idx < NCC + NC ? gc[(idx - NCC) >= 0 && (idx - NCC) < NC ? idx - NCC : 0] : cost);
       }
+      __syncthreads();
+      if (tid < RV * 8) {
+        const int v = tid >> 3, part = tid & 7, idx = round * RV + v;
+        if (idx < NV) {
+          double sacc = 0.0;
+          for (int k = 0; k < 32; ++k) sacc += Zd[v * 256 + part * 32 + k];
+          if (idx < NCC) {
+            int i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+            if (mode == 0) atomicAdd(Scc + idx, sacc);
+            if (idx == i * (i + 1) / 2 + i) atomicAdd(vhd + 6 * NFm + i, sacc);
+          } else if (idx < NCC + NC) {
+            atomicAdd(vgB + 6 * NFm + (idx - NCC), sacc);
+          } else {
+            atomicAdd(misc + 0, sacc);
+          }
+        }
+      }
+      __syncthreads();
     }
-#pragma unroll
-    for (int i = 0; i < NC; ++i) { const double s = wave_sum_dpp(gc[i]); if (lane == 63) atomicAdd(vgB + 6 * NFm + i, s); }
-    const double s = wave_sum_dpp(cost);
-    if (lane == 63) atomicAdd(misc + 0, s);
   }
   __syncthreads();
   // fold the replicas: pose x pose diagonal blocks (+ Hessian diagonal), pose gradient, camera x pose
