@@ -224,6 +224,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     if (!enable_v2 || !L.use_points) special[q] = 1;                    // camera-only / pose-only arities: v1 kernels
     if (last[q] - first[q] + 1 > Plan::NF_MAX || L.pt_nslots[q] > Plan::PASS_GROUPS) special[q] = 1;
   }
+  for (const Group& G : groups) if (G.n > 255) special[G.pt] = 1;   // the v2 slot word keeps the group size in 8 bits
 
   // --- v1 tiles from the special points' groups ---
   std::vector<uint32_t> g1;

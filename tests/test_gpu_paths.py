@@ -1,0 +1,109 @@
+"""The two sweep implementations against each other and against the oracle on problems that exercise the
+routing: v2 (LDS-window kernel, regular points) vs v1 (global-atomic kernels, the general fallback)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from lifcal_amd import BundleAdjustment, _capi as capi, scene
+from tests.helpers import S, problem, scaled_max_err, vec_err
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_CHILD = r"""
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from lifcal_amd import BundleAdjustment, _capi as capi, scene
+from tests.helpers import S
+spec = S(%s)
+sc = scene.make_scene(spec)
+with BundleAdjustment(capi.ProblemArrays.from_scene(sc)) as ba:
+    r = ba.sweep(123.0, want_matrices=True)
+    info = ba.info()
+np.savez(sys.argv[1], S=r.S, rhs=r.rhs, cost=r.cost, pg=r.point_gradient, ui=r.point_hessian_inv, chunks=info.n_chunks)
+"""
+
+
+def run_child(tmp_path, spec_args, env_extra, tag):
+    out = os.path.join(str(tmp_path), tag + ".npz")
+    env = dict(os.environ); env.update(env_extra)
+    subprocess.check_call([sys.executable, "-c", _CHILD % (ROOT, spec_args), out], env=env, cwd=ROOT)
+    return np.load(out)
+
+
+@pytest.mark.parametrize("spec_args", [
+    "24, 160, 6, 0xF06, 1201, outlier_fraction=0.02",
+    "8, 60, None, 0x506, 1202",
+    "40, 400, 9, 0xD05, 1203",
+])
+def test_v1_and_v2_kernels_agree(built, tmp_path, spec_args):
+    """same library, LIFCAL_DISABLE_V2 routes everything through the global-atomic kernels"""
+    a = run_child(tmp_path, spec_args, {}, "v2")
+    b = run_child(tmp_path, spec_args, {"LIFCAL_DISABLE_V2": "1"}, "v1")
+    assert int(a["chunks"]) > 0 and int(b["chunks"]) == 0
+    assert abs(float(a["cost"]) - float(b["cost"])) <= 1e-13 * float(b["cost"])
+    assert scaled_max_err(a["S"], b["S"]) < 1e-10 and vec_err(a["rhs"], b["rhs"]) < 1e-10
+    assert vec_err(a["pg"], b["pg"]) < 1e-11 and vec_err(a["ui"], b["ui"]) < 1e-10
+
+
+@pytest.mark.parametrize("blocks", ["1", "3", "7", "64"])
+def test_block_count_does_not_change_the_result(built, tmp_path, blocks):
+    spec_args = "30, 300, 8, 0xF06, 1204, outlier_fraction=0.02"
+    a = run_child(tmp_path, spec_args, {"LIFCAL_V2_BLOCKS": blocks}, "b" + blocks)
+    b = run_child(tmp_path, spec_args, {"LIFCAL_DISABLE_V2": "1"}, "ref")
+    assert int(a["chunks"]) >= 1
+    assert scaled_max_err(a["S"], b["S"]) < 1e-10 and vec_err(a["rhs"], b["rhs"]) < 1e-10
+
+
+def test_mixed_regular_and_oversized_points(built):
+    """a few points are also seen 25 frames later (span > 20 frame window): they take the fallback path, the rest v2"""
+    sc = scene.make_scene(S(40, 300, 8, 0xF06, 1205, outlier_fraction=0.02))
+    fr = sc.fr.copy()
+    moved = 0
+    for p in (5, 17, 40):
+        idx = np.flatnonzero(sc.pt == p)
+        f0 = sc.fr[idx].min()
+        if f0 + 27 < 40:
+            sel = idx[sc.fr[idx] == f0]
+            fr[sel] = f0 + 27; moved += len(sel)
+    assert moved > 0
+    mk = lambda: capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, fr, sc.cam0, sc.views0, sc.pts0, sc.spx, sc.scale, sc.config)
+    ref = oracle.sweep(mk(), radius=1e4, threads=4)
+    with BundleAdjustment(mk()) as ba:
+        got = ba.sweep(1e4, want_matrices=True)
+        info = ba.info()
+        s = ba.performBundleAdjustment()
+    assert info.n_chunks >= 1
+    assert abs(got.cost - ref.cost) <= 1e-12 * ref.cost
+    assert scaled_max_err(got.S, ref.S) < 1e-9 and vec_err(got.rhs, ref.rhs) < 1e-9
+    assert vec_err(got.point_gradient, ref.point_gradient) < 1e-10
+    so = oracle.solve(mk(), threads=4)
+    assert s.iterations == so.iterations and abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+
+
+def test_window_wider_than_lds_limit_falls_back(built):
+    """most points span more than the 20-frame LDS window: they are routed to the fallback kernels"""
+    sc = scene.make_scene(S(40, 60, 30, 0x506, 1206))
+    ref = oracle.sweep(problem(sc), radius=1e4, threads=4)
+    with BundleAdjustment(problem(sc)) as ba:
+        got = ba.sweep(1e4, want_matrices=True)
+    assert scaled_max_err(got.S, ref.S) < 1e-9 and vec_err(got.rhs, ref.rhs) < 1e-9
+
+
+def test_huge_group_is_not_truncated(built):
+    """300 observations of one (point, frame) pair: more than the 8-bit group size of the v2 slot word"""
+    sc = scene.make_scene(S(6, 30, None, 0x506, 1207))
+    i0 = 10
+    rep = np.full(300, i0)
+    cat = lambda a: np.concatenate([a, a[rep]])
+    noise = scene.Stream(3, 3).normal(300, 0.05)
+    u = cat(sc.u); u[-300:] += noise
+    mk = lambda: capi.ProblemArrays(u, cat(sc.v), cat(sc.mcx), cat(sc.mcy), cat(sc.pt), cat(sc.fr), sc.cam0, sc.views0, sc.pts0, sc.spx, sc.scale, sc.config)
+    ref = oracle.sweep(mk(), radius=1e4)
+    with BundleAdjustment(mk()) as ba:
+        got = ba.sweep(1e4, want_matrices=True)
+    assert abs(got.cost - ref.cost) <= 1e-12 * ref.cost and scaled_max_err(got.S, ref.S) < 1e-9
