@@ -1,0 +1,216 @@
+// bandchol.hpp — latency-oriented block-banded + arrow Cholesky of the reduced system (included by kernels.hpp).
+//
+// Replaces ceres DenseSchurComplementSolver's Eigen LLT on the dense (17+6F)^2 matrix (reference call site
+// src/CameraCalibration.cpp:956, DENSE_SCHUR) by a factorisation that only touches the co-visibility band:
+// O(F bw^2 6^3) instead of n^3/3.  The chain over the F pose blocks is inherently sequential, so ONE wave walks it
+// and everything it touches per step sits in LDS:
+//   window Wd (n_w x n_w, n_w = 6 (bw+1) + NA + 1): the frames j..j+bw as a ring (slot = frame mod (bw+1)) followed by
+//   the arrow rows (promoted points | camera | rhs).  Step j: factor the 6x6 diagonal block, scale the panel rows,
+//   rank-6 update of the window, slide (frame j+bw+1 enters from HBM).  Carrying the rhs as an arrow row makes the
+//   forward substitution part of the factorisation.
+// Each column's panel (rows below the diagonal block, 6 doubles each) is also written contiguously to Lpanel so
+// that the back-substitution streams it with coalesced loads.  Systems whose window does not fit LDS use the older
+// global-memory kernels (k_band_chol / k_band_backsolve).
+#pragma once
+
+namespace lifcal {
+
+struct BandLds {
+  uint32_t nw, off_pn, off_d, off_map, total;   // window | panel (nw x 6) | L_jj, L_jj^-1, flag | window row of each panel row
+  __host__ __device__ BandLds(uint32_t bw, uint32_t NA) {
+    nw = 6 * (bw + 1) + NA + 1;
+    off_pn = nw * nw; off_d = off_pn + nw * 6; off_map = off_d + 80; total = off_map + (nw + 1) / 2 + 1;
+  }
+};
+
+// rows of column j's panel: frames j+1..j+nbel (6 each), then the NA+1 arrow rows
+__global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
+  extern __shared__ __attribute__((aligned(16))) double bl[];
+  const uint32_t F = d.F, bw = d.bw, NAx = d.NA + 1, ld = d.ld, R = bw + 1;
+  const BandLds lay(bw, d.NA);
+  const uint32_t nw = lay.nw, arow0 = 6 * R;
+  double* Wd = bl; double* Pn = bl + lay.off_pn; double* Ld = bl + lay.off_d; double* Li = Ld + 36; double* failp = Ld + 72;
+  const uint32_t lane = threadIdx.x;   // 256 threads
+  uint32_t* wmap = (uint32_t*)(bl + lay.off_map);
+  auto slot = [&](uint32_t f) { return 6 * (f % R); };
+  if (lane == 0) *failp = 0.0;
+  // ---- load the initial window: frames 0..min(bw, F-1), all arrow rows ----
+  for (uint32_t i = lane; i < nw * nw; i += 256) Wd[i] = 0.0;
+  __syncthreads();
+  auto load_frame_row = [&](uint32_t f) {   // blocks (f, f-dd), dd = 0..min(bw, f), and the arrow entries of column f
+    const uint32_t ndd = min(bw, f) + 1;
+    for (uint32_t t = lane; t < ndd * 36; t += 256) {
+      const uint32_t dd = t / 36, e = t % 36, a = e / 6, b = e % 6;
+      if (dd == 0 && b > a) continue;
+      Wd[(size_t)(slot(f) + a) * nw + slot(f - dd) + b] = d.Sband[((size_t)f * (bw + 1) + dd) * 36 + e];
+    }
+    for (uint32_t t = lane; t < NAx * 6; t += 256) {
+      const uint32_t a = t / 6, b = t % 6;
+      Wd[(size_t)(arow0 + a) * nw + slot(f) + b] = d.Sarrow[(size_t)a * ld + 6 * f + b];
+    }
+  };
+  for (uint32_t f = 0; f < min(R, F); ++f) load_frame_row(f);
+  for (uint32_t t = lane; t < NAx * NAx; t += 256) {
+    const uint32_t a = t / NAx, b = t % NAx;
+    if (b <= a) Wd[(size_t)(arow0 + a) * nw + arow0 + b] = d.Sarrow[(size_t)a * ld + 6 * F + b];
+  }
+  __syncthreads();
+  // ---- the chain over the pose blocks ----
+  for (uint32_t j = 0; j < F; ++j) {
+    const uint32_t sj = slot(j);
+    if (lane == 0) {   // 6x6 Cholesky and the inverse of its factor
+      double L[6][6];
+      for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) L[a][b] = Wd[(size_t)(sj + a) * nw + sj + b];
+      bool ok = true;
+      for (int cI = 0; cI < 6; ++cI) {
+        double dg = L[cI][cI];
+        for (int k = 0; k < cI; ++k) dg -= L[cI][k] * L[cI][k];
+        if (!(dg > 0.0)) { ok = false; dg = 1.0; }
+        dg = sqrt(dg); L[cI][cI] = dg;
+        const double idg = 1.0 / dg;
+        for (int r = cI + 1; r < 6; ++r) { double s = L[r][cI]; for (int k = 0; k < cI; ++k) s -= L[r][k] * L[cI][k]; L[r][cI] = s * idg; }
+      }
+      if (!ok) *failp = 1.0;
+      double I[6][6];
+      for (int cI = 0; cI < 6; ++cI) {
+        for (int r = 0; r < 6; ++r) I[r][cI] = 0.0;
+        I[cI][cI] = 1.0 / L[cI][cI];
+        for (int r = cI + 1; r < 6; ++r) { double s = 0.0; for (int k = cI; k < r; ++k) s -= L[r][k] * I[k][cI]; I[r][cI] = s / L[r][r]; }
+      }
+      for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { Li[a * 6 + b] = (b <= a) ? I[a][b] : 0.0; }
+      for (int k = 0; k < 36; ++k) d.Linv[(size_t)j * 36 + k] = Li[k];
+    }
+    __syncthreads();
+    const uint32_t nbel = min(bw, F - 1 - j);
+    const uint32_t nrows = 6 * nbel + NAx;
+    double* Lp = Lpanel + (size_t)j * (6 * bw + NAx) * 6;
+    for (uint32_t r = lane; r < nrows; r += 256) {
+      const uint32_t wrow = (r < 6 * nbel) ? slot(j + 1 + r / 6) + r % 6 : arow0 + (r - 6 * nbel);
+      wmap[r] = wrow;
+      const double* src = Wd + (size_t)wrow * nw + sj;
+      double x[6], y[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) x[k] = src[k];
+#pragma unroll
+      for (int cI = 0; cI < 6; ++cI) { double s = 0.0;
+#pragma unroll
+        for (int k = 0; k <= cI; ++k) s += x[k] * Li[cI * 6 + k];
+        y[cI] = s; }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { Pn[(size_t)r * 6 + k] = y[k]; Lp[(size_t)r * 6 + k] = y[k]; }
+    }
+    __syncthreads();
+    // the frame that enters the ring after this step: issue its HBM loads now, commit them to LDS after the update
+    // (up to 2 band values + 1 arrow value per thread for bw <= 13; wider bands take the plain path below)
+    const bool has_next = (j + R < F);
+    const bool pf = has_next && (R * 36 <= 512) && (NAx * 6 <= 256);
+    double pfv[3] = {0.0, 0.0, 0.0};
+    if (pf) {
+      const uint32_t f = j + R;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) { const uint32_t t = lane + 256 * q; if (t < R * 36) pfv[q] = d.Sband[((size_t)f * (bw + 1) + t / 36) * 36 + t % 36]; }
+      if (lane < NAx * 6) pfv[2] = d.Sarrow[(size_t)(lane / 6) * ld + 6 * f + lane % 6];
+    }
+    // rank-6 update of the window: thread = (row r = tid mod 64 [+64..], column phase tid / 64), columns c <= r step 4
+    for (uint32_t r = lane & 63u; r < nrows; r += 64) {
+      const uint32_t wr = wmap[r];
+      const double* pr = Pn + (size_t)r * 6;
+      const double p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3], p4 = pr[4], p5 = pr[5];
+      for (uint32_t cI = lane >> 6; cI <= r; cI += 4) {
+        const double* pc = Pn + (size_t)cI * 6;
+        Wd[(size_t)wr * nw + wmap[cI]] -= p0 * pc[0] + p1 * pc[1] + p2 * pc[2] + p3 * pc[3] + p4 * pc[4] + p5 * pc[5];
+      }
+    }
+    __syncthreads();
+    // slide: frame j leaves its slot, frame j + bw + 1 (if any) enters it.  No zeroing is needed: every entry of the
+    // slot's row that is read later is overwritten here (all bw+1 blocks of the incoming frame), and stale entries of
+    // the slot's column are overwritten when the rows that use them enter.
+    if (has_next) {
+      const uint32_t f = j + R;
+      if (pf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const uint32_t t = lane + 256 * q;
+          if (t < R * 36) { const uint32_t dd = t / 36, e = t % 36, a = e / 6, b2 = e % 6; if (!(dd == 0 && b2 > a)) Wd[(size_t)(slot(f) + a) * nw + slot(f - dd) + b2] = pfv[q]; }
+        }
+        if (lane < NAx * 6) Wd[(size_t)(arow0 + lane / 6) * nw + slot(f) + lane % 6] = pfv[2];
+      } else {
+        load_frame_row(f);
+      }
+      __syncthreads();
+    }
+  }
+  // ---- dense Cholesky of the arrow block (NA x NA), rhs row carried along ----
+  double* Aa = Wd + (size_t)arow0 * nw + arow0;   // Aa[a * nw + b]
+  for (uint32_t cI = 0; cI < d.NA; ++cI) {
+    if (lane == 0) { double dg = Aa[(size_t)cI * nw + cI]; if (!(dg > 0.0)) { *failp = 1.0; dg = 1.0; } Aa[(size_t)cI * nw + cI] = sqrt(dg); }
+    __syncthreads();
+    const double dg = Aa[(size_t)cI * nw + cI];
+    for (uint32_t r = cI + 1 + lane; r < NAx; r += 256) Aa[(size_t)r * nw + cI] /= dg;
+    __syncthreads();
+    const uint32_t m = NAx - cI - 1;
+    for (uint32_t t = lane; t < m * (m + 1) / 2; t += 256) {
+      uint32_t a = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while (a * (a + 1) / 2 > t) --a;
+      while ((a + 1) * (a + 2) / 2 <= t) ++a;
+      const uint32_t b = t - a * (a + 1) / 2;
+      Aa[(size_t)(cI + 1 + a) * nw + cI + 1 + b] -= Aa[(size_t)(cI + 1 + a) * nw + cI] * Aa[(size_t)(cI + 1 + b) * nw + cI];
+    }
+    __syncthreads();
+  }
+  // the factor of the arrow block and y = L^-1 rhs go back to Sarrow (the back-substitution reads them there)
+  for (uint32_t t = lane; t < NAx * NAx; t += 256) {
+    const uint32_t a = t / NAx, b = t % NAx;
+    if (b <= a) d.Sarrow[(size_t)a * ld + 6 * F + b] = Aa[(size_t)a * nw + b];
+  }
+  if (lane == 0) d.step[ST_CHOL_FAIL] = *failp;
+}
+
+// L^T x = y with the packed panels: x_j = L_jj^-T (y_j - sum over the panel rows of column j)
+__global__ __launch_bounds__(64) void k_band_backsolve_w(Dev d, const double* Lpanel) {
+  extern __shared__ __attribute__((aligned(16))) double xs[];   // n_red doubles
+  const uint32_t F = d.F, bw = d.bw, NA = d.NA, NAx = NA + 1, ld = d.ld, lane = threadIdx.x;
+  const double* Aa = d.Sarrow + 6 * F;
+  // y: pose part was accumulated in the rhs arrow row of every panel (row index nrows-1 of column j's panel),
+  // arrow part sits in the factored arrow block's last row
+  for (uint32_t a = lane; a < NA; a += 64) xs[6 * F + a] = Aa[(size_t)NA * ld + a];
+  __syncthreads();
+  for (int a = (int)NA - 1; a >= 0; --a) {   // arrow block: dense back-substitution
+    if (lane == 0) xs[6 * F + a] /= Aa[(size_t)a * ld + a];
+    __syncthreads();
+    const double xa = xs[6 * F + a];
+    for (uint32_t b = lane; b < (uint32_t)a; b += 64) xs[6 * F + b] -= Aa[(size_t)a * ld + b] * xa;
+    __syncthreads();
+  }
+  for (int j = (int)F - 1; j >= 0; --j) {
+    const uint32_t nbel = min(bw, F - 1 - (uint32_t)j);
+    const uint32_t nrows = 6 * nbel + NAx;
+    const double* Lp = Lpanel + (size_t)j * (6 * bw + NAx) * 6;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    double yj[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t r = lane; r < nrows; r += 64) {
+      const double* row = Lp + (size_t)r * 6;
+      if (r == nrows - 1) {   // the rhs row of this panel holds y_j (forward substitution done by the factorisation)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) yj[k] = row[k];
+      } else {
+        const double xv = (r < 6 * nbel) ? xs[6 * ((uint32_t)j + 1 + r / 6) + r % 6] : xs[6 * F + (r - 6 * nbel)];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acc[k] += row[k] * xv;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { acc[k] = wave_sum(acc[k]); yj[k] = wave_sum(yj[k]); }
+    if (lane < 6) {
+      const double* Li = d.Linv + (size_t)j * 36;
+      double o = 0.0;   // (L^-T t)[lane] = sum_{k >= lane} Li[k][lane] t[k]
+#pragma unroll
+      for (int k = 0; k < 6; ++k) { const double tk = yj[k] - acc[k]; if (k >= (int)lane) o += Li[k * 6 + lane] * tk; }
+      xs[6 * j + lane] = o;
+    }
+    __syncthreads();
+  }
+  for (uint32_t k = lane; k < d.n_red; k += 64) d.delta_red[k] = xs[k];
+}
+
+}  // namespace lifcal

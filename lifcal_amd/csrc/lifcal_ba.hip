@@ -91,6 +91,7 @@ struct lifcal_ba_handle {
   void* comm = nullptr;
   double last_cost = 0, last_gmax = 0;
   size_t chol_lds = 0;
+  double* Lpanel = nullptr; size_t bandw_lds = 0, backw_lds = 0; bool bandw_ok = false;
   // profiling: 5 events per sweep (start, after tables, after k_sweep, before k_schur, after k_schur, end)
   std::vector<hipEvent_t> prof_events; uint32_t prof_cap = 0, prof_used = 0; bool prof_on = false;
   hipEvent_t prof_ev(int which) { return prof_events[(size_t)prof_used * 6 + which]; }
@@ -241,8 +242,13 @@ int read_sweep_scalars(lifcal_ba_handle* h, double* cost, double* gmax, double* 
 
 int launch_linear_solve(lifcal_ba_handle* h) {
   Dev& d = h->d;
-  hipLaunchKernelGGL(k_band_chol, dim3(1), dim3(1024), h->chol_lds, h->stream, d);
-  hipLaunchKernelGGL(k_band_backsolve, dim3(1), dim3(1024), 0, h->stream, d);
+  if (h->bandw_ok) {   // window and solution vector fit LDS: one wave walks the chain
+    hipLaunchKernelGGL(k_band_chol_w, dim3(1), dim3(256), h->bandw_lds, h->stream, d, h->Lpanel);
+    hipLaunchKernelGGL(k_band_backsolve_w, dim3(1), dim3(64), h->backw_lds, h->stream, d, (const double*)h->Lpanel);
+  } else {
+    hipLaunchKernelGGL(k_band_chol, dim3(1), dim3(1024), h->chol_lds, h->stream, d);
+    hipLaunchKernelGGL(k_band_backsolve, dim3(1), dim3(1024), 0, h->stream, d);
+  }
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -470,6 +476,17 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   const size_t lds_need = (80 + panel_rows * 6) * sizeof(double);
   if (lds_need <= 64 * 1024) { h->chol_lds = lds_need; d.panel_g = nullptr; }
   else { h->chol_lds = 80 * sizeof(double); A(d.panel_g, panel_rows * 6); }
+  {
+    const BandLds bl(d.bw, d.NA);
+    h->bandw_lds = (size_t)bl.total * sizeof(double);
+    h->backw_lds = (size_t)std::max(1u, d.n_red) * sizeof(double);
+    h->bandw_ok = h->bandw_lds <= 160 * 1024 && h->backw_lds <= 160 * 1024 && getenv("LIFCAL_DISABLE_BANDW") == nullptr;
+    if (h->bandw_ok) {
+      A(h->Lpanel, (size_t)std::max(1u, d.F) * (6 * (size_t)d.bw + d.NA + 1) * 6);
+      if (hipFuncSetAttribute((const void*)k_band_chol_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bandw_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
+      if (hipFuncSetAttribute((const void*)k_band_backsolve_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->backw_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
+    }
+  }
 #undef A
 #undef U
   if (hipHostMalloc((void**)&h->h_scal, (SCAL_N + 2 * ST_N + 16) * sizeof(double)) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);

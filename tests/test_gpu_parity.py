@@ -56,7 +56,8 @@ def test_solve_matches_oracle(built, name, spec):
     assert abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost
     live = 5 + (spec.config & 3) + (2 if spec.config & 4 else 0)
     assert np.allclose(pa.cam[:5], pb.cam[:5], rtol=1e-6, atol=0)
-    assert np.allclose(pa.cam[5:live], pb.cam[5:live], rtol=1e-5, atol=1e-12)
+    # distortion coefficients: 1e-6 of the vector's scale (single components can sit arbitrarily close to zero)
+    assert np.allclose(pa.cam[5:live], pb.cam[5:live], rtol=1e-6, atol=1e-6 * np.abs(pb.cam[5:live]).max() if live > 5 else 0.0)
     assert np.all(pa.cam[live:] == 0.0)
     assert np.allclose(pa.views, pb.views, rtol=0, atol=1e-6 * (1 + np.abs(pb.views).max()))
     assert np.allclose(pa.pts, pb.pts, rtol=0, atol=1e-6 * (1 + np.abs(pb.pts).max()))
