@@ -115,12 +115,12 @@ typedef struct lifcal_ba_options {
   double loss_scale;            /* 0.5: CauchyLoss(0.5) (:892) */
   int32_t max_iterations;       /* 200 (:960) */
   int32_t jacobi_scaling;       /* 1 */
-  int32_t precision;            /* 0: fp64 everywhere; 1: fp32 residual/Jacobian, fp64 accumulation */
+  int32_t precision;            /* 0: fp64 everywhere; 1 (fp32 residual/Jacobian, fp64 accumulation): NOT YET IMPLEMENTED, create() rejects it */
   int32_t device;               /* HIP device ordinal */
   int32_t rank;                 /* this process' rank in the point-sharded job (0 if single GPU) */
   int32_t world_size;           /* number of ranks (1 if single GPU) */
   int32_t verbose;              /* 1: print Ceres-style per-iteration table to stdout (:957) */
-  int32_t deterministic;        /* 1: ordered slab reduction instead of f64 atomics where offered */
+  int32_t deterministic;        /* 1 (ordered slab reduction instead of f64 atomics): NOT YET IMPLEMENTED, create() rejects it */
 } lifcal_ba_options;
 
 typedef struct lifcal_ba_summary {

@@ -386,7 +386,12 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   *out = nullptr;
   lifcal_ba_options opt; if (o) opt = *o; else lifcal_ba_default_options(&opt);
   if (opt.world_size < 1 || opt.world_size > 64 || opt.rank < 0 || opt.rank >= opt.world_size) return LIFCAL_BA_ERR_INVALID_ARG;
-  if (opt.precision != 0 && opt.precision != 1) return LIFCAL_BA_ERR_INVALID_ARG;
+  if (opt.precision != 0 || opt.deterministic != 0) {
+    // declared in the ABI for BASELINE configs[4] (fp32 residual/Jacobian) and for ordered reductions; neither exists yet,
+    // and silently running the fp64 / atomic path instead would misreport what was measured
+    g_last_error = "options.precision = 1 and options.deterministic = 1 are not implemented in this version";
+    return LIFCAL_BA_ERR_INVALID_ARG;
+  }
   lifcal_ba_handle* h = new (std::nothrow) lifcal_ba_handle();
   if (!h) return LIFCAL_BA_ERR_NOMEM;
   h->opt = opt;
