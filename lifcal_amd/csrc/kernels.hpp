@@ -71,6 +71,7 @@ struct Dev {
   double *Sband, *Sarrow, *rhsacc, *gB, *hdiag, *scal;
   double *sig_red, *lam_red, *delta_red, *Linv;  // n_red, n_red, n_red, 36F
   double* step;                  // ST_N scalars
+  double* dP;                    // 3P: unscaled point step of the last back-substitution (line search re-applies it)
   unsigned long long* dbg;       // diagnostic build only (LIFCAL_STAMPS): per-block phase cycle counts
 };
 
@@ -763,6 +764,7 @@ __global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by th
         const double dl = -(iv[3 * k] * v[0] + iv[3 * k + 1] * v[1] + iv[3 * k + 2] * v[2]);
         const double xo = d.pts[3 * (size_t)p + k];
         d.pts_c[3 * (size_t)p + k] = xo + dl;
+        d.dP[3 * (size_t)p + k] = dl;
         gtd += acc[6 + k] * dl; ddd += d.lamP[3 * (size_t)p + k] * dl * dl; st2 += dl * dl; x2 += xo * xo;
       }
     }
@@ -780,6 +782,60 @@ __global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by th
   }
   gtd = wave_sum(gtd); ddd = wave_sum(ddd); st2 = wave_sum(st2); x2 = wave_sum(x2);
   if ((threadIdx.x & 63) == 0) { atomicAdd(partial + 0, gtd); atomicAdd(partial + 1, ddd); atomicAdd(partial + 2, st2); atomicAdd(partial + 3, x2); }
+}
+
+// candidate = Plus(x, t * delta) for an arbitrary step length t (ceres ParameterBlock::Plus incl. box projection), from
+// the stored reduced solution and point step; out[0] += |x - candidate|^2, out[1] += |x|^2 over this rank's share
+__global__ void k_apply_step(Dev d, double t, double* out_local, double* out_points) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t F6 = 6 * d.F, camcol = F6 + 3 * d.Q;
+  double st2r = 0.0, x2r = 0.0, st2p = 0.0, x2p = 0.0;
+  if (i < F6) {
+    const double xo = d.views[i], xn = xo + t * d.delta_red[i];
+    d.views_c[i] = xn;
+    if (d.use_poses && d.frame_live[i / 6]) { st2r += (xn - xo) * (xn - xo); x2r += xo * xo; }
+  }
+  if (i < LIFCAL_BA_MAX_CAMERA_PARAMETERS) {
+    const double xo = d.cam[i];
+    double xn = xo;
+    if (i < d.nc && d.camc->chm[i] != 0.0) xn = xo + t * d.delta_red[camcol + i];
+    if (d.lower && xn < d.lower[i]) xn = d.lower[i];
+    if (d.upper && xn > d.upper[i]) xn = d.upper[i];
+    d.cam_c[i] = xn;
+    st2r += (xn - xo) * (xn - xo); x2r += xo * xo;
+  }
+  if (d.use_points) {
+    if (i < d.n_owned) {
+      const uint32_t p = d.owned[i];
+      if (d.promoted[p] < 0) for (int k = 0; k < 3; ++k) {
+        const double xo = d.pts[3 * (size_t)p + k], dl = t * d.dP[3 * (size_t)p + k];
+        d.pts_c[3 * (size_t)p + k] = xo + dl; st2p += dl * dl; x2p += xo * xo;
+      }
+    }
+    if (i < d.Q) {
+      const uint32_t pid = d.promoted_ids[i];
+      for (int k = 0; k < 3; ++k) {
+        const double xo = d.pts[3 * (size_t)pid + k], dl = t * d.delta_red[F6 + 3 * i + k];
+        d.pts_c[3 * (size_t)pid + k] = xo + dl;
+        if (d.rank == 0) { st2p += dl * dl; x2p += xo * xo; }
+      }
+    }
+  }
+  st2r = wave_sum(st2r); x2r = wave_sum(x2r); st2p = wave_sum(st2p); x2p = wave_sum(x2p);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(out_local + 0, st2r); atomicAdd(out_local + 1, x2r); atomicAdd(out_points + 0, st2p); atomicAdd(out_points + 1, x2p); }
+}
+
+// directional derivative grad(x_trial) . delta after a sweep at the trial point: reduced part (replicated) and point part
+__global__ void k_dirderiv(Dev d, double* out_local, double* out_points) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  double dr = 0.0, dp = 0.0;
+  if (i < d.n_red) dr = d.gB[i] * d.delta_red[i];
+  if (d.use_points && i < d.n_owned) {
+    const uint32_t p = d.owned[i];
+    if (d.promoted[p] < 0) { const double* g = d.ptacc + (size_t)p * 36 + 6; for (int k = 0; k < 3; ++k) dp += g[k] * d.dP[3 * (size_t)p + k]; }
+  }
+  dr = wave_sum(dr); dp = wave_sum(dp);
+  if ((threadIdx.x & 63) == 0) { atomicAdd(out_local, dr); atomicAdd(out_points, dp); }
 }
 
 // ---------------------------------------------------------------------------------------------

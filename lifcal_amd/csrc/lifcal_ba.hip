@@ -23,6 +23,7 @@
 #include "../../include/lifcal_ba.h"
 #include "kernels.hpp"
 #include "plan.hpp"
+#include "linesearch.hpp"
 
 using namespace lifcal;
 
@@ -91,6 +92,7 @@ struct lifcal_ba_handle {
   void* comm = nullptr;
   double last_cost = 0, last_gmax = 0;
   size_t chol_lds = 0;
+  double* ls_buf = nullptr;      // line search scalars: [0] step2 [1] x2 (local) | [2] step2 [3] x2 [4] dir (points, all-reduced) | [5] dir (local)
   double* Lpanel = nullptr; size_t bandw_lds = 0, backw_lds = 0; bool bandw_ok = false;
   // profiling: 5 events per sweep (start, after tables, after k_sweep, before k_schur, after k_schur, end)
   std::vector<hipEvent_t> prof_events; uint32_t prof_cap = 0, prof_used = 0; bool prof_on = false;
@@ -272,6 +274,45 @@ int launch_candidate(lifcal_ba_handle* h) {
   if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
   HIP_TRY(hipGetLastError());
   if (int rc = do_allreduce(h, h->partial, 8)) return rc;
+  return 0;
+}
+
+// ---- Armijo line search (bounded problems) ---------------------------------------------------------------------
+// candidate = Plus(x, t delta); returns |x - candidate|^2 and |x|^2 in ls_buf
+int launch_apply_step(lifcal_ba_handle* h, double t) {
+  Dev& d = h->d;
+  HIP_TRY(hipMemsetAsync(h->ls_buf, 0, 8 * sizeof(double), h->stream));
+  const uint32_t n = std::max(std::max(6 * d.F, 17u), std::max(d.n_owned, d.Q));
+  hipLaunchKernelGGL(k_apply_step, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, t, h->ls_buf, h->ls_buf + 2);
+  HIP_TRY(hipGetLastError());
+  return 0;
+}
+
+// phi(t) and phi'(t): one fused sweep at the trial point gives cost and gradient (the blocks of the current point
+// are overwritten: the step, its model cost and the stored deltas have already been read)
+int eval_trial(lifcal_ba_handle* h, double t, double radius, LsSample* smp) {
+  Dev& d = h->d;
+  if (int rc = launch_apply_step(h, t)) return rc;
+  auto swap_all = [&]() { std::swap(d.cam, d.cam_c); std::swap(d.views, d.views_c); if (d.use_points) std::swap(d.pts, d.pts_c); };
+  swap_all();
+  int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true, h->red_block, h->red_count, d.step, ST_N);
+  if (!rc) rc = launch_blocks(h, radius, 0, true);
+  if (!rc && d.use_points && d.n_special) { hipLaunchKernelGGL(k_schur, dim3((d.n_special + 3) / 4), dim3(256), 0, h->stream, d, radius); }
+  if (!rc) rc = do_allreduce(h, h->red_block, h->red_count);
+  if (!rc) {
+    const uint32_t n = std::max(d.n_red, d.n_owned);
+    hipLaunchKernelGGL(k_dirderiv, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, h->ls_buf + 5, h->ls_buf + 4);
+    if (hipGetLastError() != hipSuccess) rc = LIFCAL_BA_ERR_HIP;
+  }
+  swap_all();
+  if (rc) return rc;
+  if (int rc2 = do_allreduce(h, h->ls_buf + 2, 3)) return rc2;
+  double hb[8], cost;
+  HIP_TRY(hipMemcpyAsync(hb, h->ls_buf, sizeof(hb), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(&cost, d.scal + SCAL_COST, sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  smp->x = t; smp->value = cost; smp->value_valid = std::isfinite(cost);
+  smp->gradient = hb[4] + hb[5]; smp->gradient_valid = smp->value_valid && std::isfinite(smp->gradient);
   return 0;
 }
 
@@ -475,6 +516,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   d.Sband = h->red_block; d.Sarrow = d.Sband + n_band; d.rhsacc = d.Sarrow + n_arrow; d.gB = d.rhsacc + d.n_red; d.hdiag = d.gB + d.n_red; d.scal = d.hdiag + d.n_red;
   A(d.sig_red, d.n_red); A(d.lam_red, d.n_red); A(d.delta_red, d.n_red); A(d.Linv, (size_t)d.F * 36 + 36);
   A(d.dbg, (size_t)std::max(1u, d.n_blocks) * 8);
+  A(d.dP, 3 * (size_t)d.P); A(h->ls_buf, 8);
   A(d.step, ST_N); A(h->partial, 8); A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->pts_gather, 3 * (size_t)d.P);
   // Cholesky panel: LDS when it fits (<= 64 KiB by default launch limits), else a global scratch
   const size_t panel_rows = 6 * (size_t)d.bw + d.NA + 1;
@@ -703,7 +745,65 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
     invalid_steps = 0;
     double cand_cost = st.cand_cost;
     if (!std::isfinite(cand_cost)) cand_cost = std::numeric_limits<double>::max();
-    const double step_norm = std::sqrt(st.step2), x_norm = std::sqrt(st.x2);
+    double step2 = st.step2, x2 = st.x2;
+    if (h->constrained) {
+      // ceres TrustRegionMinimizer::DoLineSearch: Armijo along the projected step, CUBIC interpolation, at most 20 trials;
+      // phi(1) is the candidate cost already evaluated, the gradient at a trial point is only needed when the test fails
+      const double g0 = st.gtd;
+      const double suff = 1e-4;
+      bool armijo_ok = std::isfinite(st.cand_cost) && st.cand_cost <= x_cost + suff * g0 * 1.0;
+      if (!armijo_ok) {
+        LsSample init, prev, cur;
+        init.x = 0; init.value = x_cost; init.gradient = g0; init.value_valid = init.gradient_valid = true;
+        if (int rc = eval_trial(h, 1.0, radius, &cur)) return rc;
+        // max |delta| for the minimum-step test
+        std::vector<double> dr(h->d.n_red), dp(3 * (size_t)h->d.P);
+        HIP_TRY(hipMemcpy(dr.data(), h->d.delta_red, dr.size() * 8, hipMemcpyDeviceToHost));
+        if (h->d.use_points && h->d.P) HIP_TRY(hipMemcpy(dp.data(), h->d.dP, dp.size() * 8, hipMemcpyDeviceToHost));
+        double dir_max = 0; for (double vv : dr) dir_max = std::max(dir_max, std::fabs(vv));
+        if (h->d.use_points) for (uint32_t q : h->plan.owned_points) if (h->plan.promoted[q] < 0) for (int k = 0; k < 3; ++k) dir_max = std::max(dir_max, std::fabs(dp[3 * (size_t)q + k]));
+        int ls_iter = 0; bool ls_ok = true;
+        while (!cur.value_valid || cur.value > x_cost + suff * g0 * cur.x) {
+          if (++ls_iter >= 20) { ls_ok = false; break; }
+          const double lo_b = 1e-3 * cur.x, hi_b = 0.6 * cur.x;
+          double tnew;
+          if (!cur.value_valid) tnew = std::min(std::max(cur.x * 0.5, lo_b), hi_b);
+          else { std::vector<LsSample> smp{init, cur}; if (prev.value_valid) smp.push_back(prev); tnew = ls_minimize(smp, lo_b, hi_b); }
+          if (tnew * dir_max < 1e-9) { ls_ok = false; break; }
+          prev = cur;
+          if (int rc = eval_trial(h, tnew, radius, &cur)) return rc;
+        }
+        const double t_opt = ls_ok ? cur.x : 1.0;
+        // candidate at the chosen step length, its cost and the step norm (the model cost change stays that of the full step)
+        if (int rc = launch_apply_step(h, t_opt)) return rc;
+        HIP_TRY(hipMemsetAsync(h->partial, 0, 8 * sizeof(double), h->stream));
+        if (int rc = launch_tables(h, h->d.cam_c, h->d.views_c, h->d.camc_c, h->d.ft_c, h->d.lt_c, false, true)) return rc;
+        {
+          Dev& d = h->d;
+          const double* pts_eval = d.use_points ? d.pts_c : d.pts;
+          for (const TileSet* ts : {&h->ts1, &h->ts2}) {
+            if (!ts->n_tiles) continue;
+            const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 2048u));
+#define CALL_COST2(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)d.camc_c, (const double*)d.ft_c, (const double*)d.lt_c, pts_eval, h->partial + 4)
+            DISPATCH_CFG(h, CALL_COST2);
+#undef CALL_COST2
+          }
+          if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
+          HIP_TRY(hipGetLastError());
+          if (int rc = do_allreduce(h, h->partial, 8)) return rc;
+          if (int rc = do_allreduce(h, h->ls_buf + 2, 2)) return rc;
+          double hb[8], hp[8];
+          HIP_TRY(hipMemcpyAsync(hb, h->ls_buf, sizeof(hb), hipMemcpyDeviceToHost, h->stream));
+          HIP_TRY(hipMemcpyAsync(hp, h->partial, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+          HIP_TRY(hipStreamSynchronize(h->stream));
+          cand_cost = std::isfinite(hp[4]) ? hp[4] : std::numeric_limits<double>::max();
+          step2 = hb[0] + hb[2]; x2 = hb[1] + hb[3];
+        }
+        system_ready = false;   // the trial sweeps overwrote the blocks of the current point
+        if (getenv("LIFCAL_DEBUG_LS")) fprintf(stderr, "[lifcal_ba] line search: %d backtracks, t = %.6g\n", ls_iter, t_opt);
+      }
+    }
+    const double step_norm = std::sqrt(step2), x_norm = std::sqrt(x2);
     if (step_norm <= o.parameter_tolerance * (x_norm + o.parameter_tolerance)) { s->termination = LIFCAL_BA_TERM_PARAMETER_TOLERANCE; break; }
     const double cost_change = x_cost - cand_cost;
     if (std::fabs(cost_change) <= o.function_tolerance * x_cost) { s->termination = LIFCAL_BA_TERM_FUNCTION_TOLERANCE; break; }

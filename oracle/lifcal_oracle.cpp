@@ -25,6 +25,7 @@
 #include <complex>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <thread>
@@ -900,6 +901,7 @@ int lo_solve(const lifcal_ba_problem* p, const lifcal_ba_options* o, int threads
         if (step * dir_max < 1e-9) { ls_ok = false; break; }
         prev = cur; phi(step, &cur);
       }
+      if (ls_iter > 0 && getenv("LO_DEBUG_LS")) fprintf(stderr, "[oracle] line search: %d backtracks, t = %.6g ok=%d\n", ls_iter, cur.x, (int)ls_ok);
       if (ls_ok) { for (auto& v : delta.cam) v *= cur.x; for (auto& v : delta.view) v *= cur.x; for (auto& v : delta.pt) v *= cur.x; }
     }
     plus(s, x, delta, &cand);

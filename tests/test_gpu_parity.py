@@ -157,3 +157,46 @@ def test_invalid_arguments_fail_loudly(built):
     with BundleAdjustment(problem(sc)) as ba:
         with pytest.raises(LifcalError):
             ba.sweep(-1.0)
+
+
+@pytest.mark.parametrize("seed", [1311, 1312])
+def test_active_bounds_trigger_the_line_search(built, seed):
+    """camera-only problem with box bounds that cut off the minimiser: the projected LM step fails ceres' Armijo test,
+    so TrustRegionMinimizer::DoLineSearch backtracks (cubic interpolation).  The GPU path must follow the oracle's
+    trajectory through those searches (the oracle was checked to backtrack on these seeds: LO_DEBUG_LS=1)."""
+    cfg = 0x006
+    sc = scene.make_scene(S(6, 60, None, cfg, seed))
+    lower = np.full(17, -np.inf); upper = np.full(17, np.inf)
+    if sc.cam0[3] < sc.cam_gt[3]: upper[3] = sc.cam0[3] + 0.3
+    else: lower[3] = sc.cam0[3] - 0.3
+    gap = 0.3 * abs(sc.cam_gt[1] - sc.cam0[1])
+    if sc.cam0[1] < sc.cam_gt[1]: upper[1] = sc.cam0[1] + gap
+    else: lower[1] = sc.cam0[1] - gap
+    mk = lambda: capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, sc.cam0, sc.views_gt, sc.pts_gt, sc.spx, sc.scale, cfg, lower=lower, upper=upper)
+    pa, pb = mk(), mk()
+    with BundleAdjustment(pa) as ba:
+        s = ba.performBundleAdjustment()
+    so = oracle.solve(pb, threads=4)
+    assert (s.iterations, s.successful_steps, s.unsuccessful_steps, s.termination) == (so.iterations, so.successful_steps, so.unsuccessful_steps, so.termination)
+    assert abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert np.allclose(pa.cam[:5], pb.cam[:5], rtol=1e-6)
+    assert np.all(pa.cam >= lower - 1e-12) and np.all(pa.cam <= upper + 1e-12)
+
+
+def test_bounded_pose_point_problem_matches_oracle(built):
+    """poses and points free, intrinsics boxed (the recalib pattern with a tight box): trial points go through k_sweep2"""
+    sc = scene.make_scene(S(8, 60, None, 0xF06, 1320, outlier_fraction=0.02))
+    lower = np.full(17, -np.inf); upper = np.full(17, np.inf)
+    for k in (1, 3, 4):
+        lower[k] = sc.cam0[k] - 0.05 * abs(sc.cam_gt[k] - sc.cam0[k]) - 1e-3
+        upper[k] = sc.cam0[k] + 0.05 * abs(sc.cam_gt[k] - sc.cam0[k]) + 1e-3
+    mk = lambda: capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, sc.cam0, sc.views0, sc.pts0, sc.spx, sc.scale, sc.config,
+                                    fixed_mask=0b101, lower=lower, upper=upper)
+    pa, pb = mk(), mk()
+    with BundleAdjustment(pa) as ba:
+        s = ba.performBundleAdjustment()
+    so = oracle.solve(pb, threads=4)
+    assert (s.iterations, s.termination) == (so.iterations, so.termination)
+    assert abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert pa.cam[0] == sc.cam0[0] and pa.cam[2] == sc.cam0[2]
+    assert np.allclose(pa.cam[:5], pb.cam[:5], rtol=1e-6)
