@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
+                    help="rccl: library-owned RCCL communicator (default, one GPU per rank); gloo: rehearsal of the multi-process path on ONE GPU (all ranks on cuda:0, all-reduce through host memory)")
     args = ap.parse_args()
 
     import torch
@@ -102,13 +104,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the bundle-adjustment path has no CPU fallback")
+    if args.comm == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.comm == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     spec = scene.baseline_spec(args.workload)
     sc = scene.make_scene(spec)
@@ -119,12 +126,27 @@ def main():
     o.rank = rank
     o.world_size = world
     ba = BundleAdjustment(pa, o)
-    if world > 1:
+    if world > 1 and args.comm == "rccl":
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).cuda()
         dist.broadcast(uid, src=0)
         ba.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()))
+    elif world > 1:
+        import ctypes as C
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+        def hook(ptr, count, stream):
+            hip.hipStreamSynchronize(stream)
+            buf = np.empty(count)
+            hip.hipMemcpy(buf.ctypes.data, ptr, count * 8, 2)
+            t = torch.from_numpy(buf)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            hip.hipMemcpy(ptr, buf.ctypes.data, count * 8, 1)
+            return 0
+        ba.set_allreduce(hook)
     info = ba.info()
     radius = 1e4
 
@@ -146,7 +168,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.comm == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     last = ba.sweep(radius)
@@ -172,7 +194,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {F_tot} frames, {P_tot} points, {n_obs_total} micro-image observations, "
                                    f"window {spec.window}, config {spec.config:#x} (2 radial + tangential, mlCenterAdj, Cauchy(0.5), refine poses+points)",
-                       "obs_per_gpu": n_loc, "n_reduced": n_red, "sharding": "by 3D point" if world > 1 else "single GPU"},
+                       "obs_per_gpu": n_loc, "n_reduced": n_red, "sharding": "by 3D point" if world > 1 else "single GPU", "comm": args.comm if world > 1 else None},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (residual+Jacobian+block accumulation)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
                          "traffic": load_traffic(args.workload),
