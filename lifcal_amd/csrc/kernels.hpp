@@ -343,6 +343,31 @@ __global__ __launch_bounds__(256) void k_sweep(Dev d) {
   }
 }
 
+// one column of the reduced system: ceres LevenbergMarquardtStrategy diagonal (clamp(sigma^2 h) / (radius sigma^2) in the
+// unscaled space), rhs = -g_B + W^T U^-1 g into the rhs arrow row, identity for columns that are not solved for
+LIFCAL_DEV void finalize_column(const Dev& d, uint32_t t, double radius) {
+  const uint32_t F6 = 6 * d.F;
+  bool live;
+  if (t < F6) live = d.use_poses && d.frame_live[t / 6];
+  else if (t < F6 + 3 * d.Q) live = true;
+  else live = d.camc->chm[t - F6 - 3 * d.Q] != 0.0;
+  double* diag = s_addr(d, t, t);
+  double* rhs = d.Sarrow + (size_t)d.NA * d.ld;  // extra arrow row carries the right-hand side
+  if (live) {
+    const double s = d.sig_red[t];
+    const double lam = fmin(fmax(d.hdiag[t] * s * s, d.lm_min), d.lm_max) / (radius * s * s);
+    d.lam_red[t] = lam;
+    *diag += lam;
+    rhs[t] = -d.gB[t] + d.rhsacc[t];
+  } else {
+    d.lam_red[t] = 0.0;
+    *diag = 1.0;
+    rhs[t] = 0.0;
+  }
+  // max |g| over the reduced block (bit pattern of a non-negative double orders like an integer)
+  atomicMax((unsigned long long*)(d.step + ST_GMAX_RED), (unsigned long long)__double_as_longlong(fabs(d.gB[t])));
+}
+
 }  // namespace lifcal
 #include "sweep2.hpp"   // k_sweep2: the LDS-window fused sweep (regular points)
 namespace lifcal {
@@ -524,27 +549,7 @@ __global__ __launch_bounds__(256) void k_schur(Dev d, double radius) {
 // ---------------------------------------------------------------------------------------------
 __global__ void k_finalize(Dev d, double radius) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= d.n_red) return;
-  const uint32_t F6 = 6 * d.F;
-  bool live;
-  if (t < F6) live = d.use_poses && d.frame_live[t / 6];
-  else if (t < F6 + 3 * d.Q) live = true;
-  else live = d.camc->chm[t - F6 - 3 * d.Q] != 0.0;
-  double* diag = s_addr(d, t, t);
-  double* rhs = d.Sarrow + (size_t)d.NA * d.ld;  // extra arrow row carries the right-hand side
-  if (live) {
-    const double s = d.sig_red[t];
-    const double lam = fmin(fmax(d.hdiag[t] * s * s, d.lm_min), d.lm_max) / (radius * s * s);
-    d.lam_red[t] = lam;
-    *diag += lam;
-    rhs[t] = -d.gB[t] + d.rhsacc[t];
-  } else {
-    d.lam_red[t] = 0.0;
-    *diag = 1.0;
-    rhs[t] = 0.0;
-  }
-  // max |g| over the reduced block (bit pattern of a non-negative double orders like an integer)
-  atomicMax((unsigned long long*)(d.step + ST_GMAX_RED), (unsigned long long)__double_as_longlong(fabs(d.gB[t])));
+  if (t < d.n_red) finalize_column(d, t, radius);
 }
 
 // ---------------------------------------------------------------------------------------------

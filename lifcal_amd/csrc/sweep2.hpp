@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
   for (uint32_t cI = tid; cI < ncolp; cI += 256)
     colinfo[cI] = (cI < 6 * nf) ? (unsigned short)(((cI / 6) << 8) | (cI % 6)) : (cI < ncol - 1 ? (unsigned short)(0x8000u | (cI - 6 * nf)) : (unsigned short)0xC000u);
   double cc[NCC], gc[NC], cost = 0.0;
+  double lmant = 1.0; int lexp = 0;   // product of the Cauchy arguments of this lane's observations
 #pragma unroll
   for (int i = 0; i < NCC; ++i) cc[i] = 0.0;
 #pragma unroll
@@ -146,10 +147,11 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
           obs_eval<NR, TAN, ADJ>(c, gcn, L, u, v, r, Jq, Jc);
           const double sq = r[0] * r[0] + r[1] * r[1];
           if (d.robust) {  // ceres::CauchyLoss + Corrector with rho'' < 0: scale r and J by sqrt(rho')
+            // rho = b log(1 + s/b): the lane keeps the running PRODUCT of (1 + s/b) as mantissa x 2^exponent and takes one
+            // log at the end; sqrt(rho') = rsqrt(1 + s/b)
             const double sum = 1.0 + sq * c.loss_c;
-            const double inv = 1.0 / sum;
-            cost += 0.5 * c.loss_b * log(sum);
-            const double sc = sqrt(fmax(inv, 2.2250738585072014e-308));
+            int ex; lmant = frexp(lmant * sum, &ex); lexp += ex;
+            const double sc = rsqrt(sum);
             r[0] *= sc; r[1] *= sc;
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -393,6 +395,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     __syncthreads();
     STAMP(4);
   }
+  if (d.robust) cost += 0.5 * c.loss_b * (log(lmant) + (double)lexp * 0.6931471805599453);
   // ---------------- camera x camera block, camera gradient, cost: 256-way reduction through LDS ----------------
   // every thread parks its partial sums as [value][thread] in the (now free) Zd region, 8 threads per value add them up
   {
