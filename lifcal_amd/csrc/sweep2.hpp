@@ -104,6 +104,89 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #pragma unroll
   for (int i = 0; i < NC; ++i) gc[i] = 0.0;
 
+  // ---- Schur product helpers: window -= Zd^T Zd in 4x4 micro-tiles over the lower triangle, one owner per output entry ----
+  const uint32_t nmt = (ncol + 3u) >> 2;               // micro-tile rows/cols that contain real columns
+  const uint32_t ntri = nmt * (nmt + 1) / 2;
+  auto tri_decode = [](uint32_t t, uint32_t& mi, uint32_t& mj) {
+    mi = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (mi * (mi + 1) / 2 > t) --mi;
+    while ((mi + 1) * (mi + 2) / 2 <= t) ++mi;
+    mj = t - mi * (mi + 1) / 2;
+  };
+  auto gemm_tile = [&](uint32_t mi, uint32_t mj, uint32_t krows, double (&acc16)[4][4]) {
+    const double* za = Zd + 4 * mi;
+    const double* zb = Zd + 4 * mj;
+    // four rows of Zd per step (16 ds_read_b128, 64 FMAs), software-pipelined: the reads of step k+1 are issued before
+    // the FMAs of step k (one wave per SIMD: nothing else hides the LDS latency); rows beyond 3 np are zero because
+    // krows is rounded up to 4 and the pass zero-fills them
+    double2 cur[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cur[r][0] = *reinterpret_cast<const double2*>(za + (size_t)r * zs);
+      cur[r][1] = *reinterpret_cast<const double2*>(za + (size_t)r * zs + 2);
+      cur[r][2] = *reinterpret_cast<const double2*>(zb + (size_t)r * zs);
+      cur[r][3] = *reinterpret_cast<const double2*>(zb + (size_t)r * zs + 2);
+    }
+#pragma unroll 2
+    for (uint32_t k0 = 0; k0 < krows; k0 += 4) {
+      double2 nxt[4][4];
+      const uint32_t kn = (k0 + 4 < krows) ? k0 + 4 : k0;   // the last step re-reads its own rows
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        nxt[r][0] = *reinterpret_cast<const double2*>(za + (size_t)(kn + r) * zs);
+        nxt[r][1] = *reinterpret_cast<const double2*>(za + (size_t)(kn + r) * zs + 2);
+        nxt[r][2] = *reinterpret_cast<const double2*>(zb + (size_t)(kn + r) * zs);
+        nxt[r][3] = *reinterpret_cast<const double2*>(zb + (size_t)(kn + r) * zs + 2);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double av[4] = {cur[r][0].x, cur[r][0].y, cur[r][1].x, cur[r][1].y};
+        const double bq[4] = {cur[r][2].x, cur[r][2].y, cur[r][3].x, cur[r][3].y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc16[i][j] += av[i] * bq[j];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[r][q] = nxt[r][q];
+    }
+  };
+  auto emit_tile = [&](uint32_t mi, uint32_t mj, const double (&acc16)[4][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t ci = 4 * mi + i;
+      const uint32_t ii = colinfo[ci < ncolp ? ci : 0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t cj = 4 * mj + j;
+        const double dv = acc16[i][j];
+        if (ci >= ncol || cj >= ncol || ci < cj) continue;
+        const uint32_t jj = colinfo[cj];
+        if (!(ii & 0x8000u)) {            // pose x pose
+          const uint32_t lfi = ii >> 8, lfj = jj >> 8;
+          Spp[(size_t)(lfi * (lfi + 1) / 2 + lfj) * 36 + (ii & 0xFFu) * 6 + (jj & 0xFFu)] -= dv;
+        } else if (!(ii & 0x4000u)) {     // camera row
+          const uint32_t jc = ii & 0xFFu;
+          if (!(jj & 0x8000u)) Scp[(size_t)jc * 6 * NFm + cj] -= dv;
+          else Scc[jc * (jc + 1) / 2 + (jj & 0xFFu)] -= dv;
+        } else if (cj < ncol - 1) {       // rhs row: W^T U^-1 g
+          if (!(jj & 0x8000u)) vrhs[cj] += dv; else vrhs[6 * NFm + (jj & 0xFFu)] += dv;
+        }
+      }
+    }
+  };
+  // when the triangle has at most one tile per thread, the tile is accumulated over all passes of the block in registers
+  const bool keep_tiles = (mode == 0) && ntri <= 256;
+  uint32_t mi0 = 0, mj0 = 0;
+  if (keep_tiles && tid < ntri) tri_decode(tid, mi0, mj0);
+  double tacc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tacc[i][j] = 0.0;
+
   for (uint32_t ps = d.blk_pass0[b]; ps < d.blk_pass0[b + 1]; ++ps) {
     const uint32_t np = d.pass_np[ps], pt0 = d.pass_pt0[ps], gid0 = d.pass_gid0[ps];
     const uint32_t krows = (3 * np + 3u) & ~3u;   // K of the product, multiple of 4
@@ -333,68 +416,25 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
       // Register-blocked fp64 product on the vector ALUs: measured on gfx950, v_fmac_f64 (6.3 cycles per wave
       // instruction, 64 MAC) outruns v_mfma_f64_16x16x4_f64 (~140 cycles, 1024 MAC) by ~1.4x, so the product
       // runs as 4x4 micro-tiles per lane over the lower triangle; each output entry has exactly one owner.
-      const uint32_t nmt = (ncol + 3u) >> 2;               // micro-tile rows/cols that contain real columns
-      const uint32_t ntri = nmt * (nmt + 1) / 2;
-      for (uint32_t t = tid; t < ntri; t += 256) {
-        uint32_t mi = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while (mi * (mi + 1) / 2 > t) --mi;
-        while ((mi + 1) * (mi + 2) / 2 <= t) ++mi;
-        const uint32_t mj = t - mi * (mi + 1) / 2;
-        double acc16[4][4];
+      if (keep_tiles) {
+        if (tid < ntri) gemm_tile(mi0, mj0, krows, tacc);     // the tile stays in registers until the block's last pass
+      } else {
+        for (uint32_t t = tid; t < ntri; t += 256) {
+          uint32_t mi, mj; tri_decode(t, mi, mj);
+          double acc16[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+          for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc16[i][j] = 0.0;
-        const double* za = Zd + 4 * mi;
-        const double* zb = Zd + 4 * mj;
-        // four rows of Zd per step: 16 ds_read_b128 in flight, then 64 FMAs (one wave per SIMD: the only way to amortise
-        // the LDS latency); rows beyond 3 np are zero because krows is rounded up to 4 and the pass zero-fills them
-        for (uint32_t k0 = 0; k0 < krows; k0 += 4) {
-          double2 aq[4][2], bq2[4][2];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            aq[r][0] = *reinterpret_cast<const double2*>(za + (size_t)(k0 + r) * zs);
-            aq[r][1] = *reinterpret_cast<const double2*>(za + (size_t)(k0 + r) * zs + 2);
-            bq2[r][0] = *reinterpret_cast<const double2*>(zb + (size_t)(k0 + r) * zs);
-            bq2[r][1] = *reinterpret_cast<const double2*>(zb + (size_t)(k0 + r) * zs + 2);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const double av[4] = {aq[r][0].x, aq[r][0].y, aq[r][1].x, aq[r][1].y};
-            const double bq[4] = {bq2[r][0].x, bq2[r][0].y, bq2[r][1].x, bq2[r][1].y};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) acc16[i][j] += av[i] * bq[j];
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const uint32_t ci = 4 * mi + i;
-          const uint32_t ii = colinfo[ci < ncolp ? ci : 0];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t cj = 4 * mj + j;
-            const double dv = acc16[i][j];
-            if (ci >= ncol || cj >= ncol || ci < cj) continue;
-            const uint32_t jj = colinfo[cj];
-            if (!(ii & 0x8000u)) {            // pose x pose
-              const uint32_t lfi = ii >> 8, lfj = jj >> 8;
-              Spp[(size_t)(lfi * (lfi + 1) / 2 + lfj) * 36 + (ii & 0xFFu) * 6 + (jj & 0xFFu)] -= dv;
-            } else if (!(ii & 0x4000u)) {     // camera row
-              const uint32_t jc = ii & 0xFFu;
-              if (!(jj & 0x8000u)) Scp[(size_t)jc * 6 * NFm + cj] -= dv;
-              else Scc[jc * (jc + 1) / 2 + (jj & 0xFFu)] -= dv;
-            } else if (cj < ncol - 1) {       // rhs row: W^T U^-1 g
-              if (!(jj & 0x8000u)) vrhs[cj] += dv; else vrhs[6 * NFm + (jj & 0xFFu)] += dv;
-            }
-          }
+            for (int j = 0; j < 4; ++j) acc16[i][j] = 0.0;
+          gemm_tile(mi, mj, krows, acc16);
+          emit_tile(mi, mj, acc16);
         }
       }
     }
     __syncthreads();
     STAMP(4);
   }
+  if (keep_tiles && tid < ntri) emit_tile(mi0, mj0, tacc);   // (colinfo and the window are only read/written by owners: no barrier needed before)
   if (d.robust) cost += 0.5 * c.loss_b * (log(lmant) + (double)lexp * 0.6931471805599453);
   // ---------------- camera x camera block, camera gradient, cost: 256-way reduction through LDS ----------------
   // every thread parks its partial sums as [value][thread] in the (now free) Zd region, 8 threads per value add them up
