@@ -413,7 +413,7 @@ int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size,
   Plan pl;
   if (int rc = build_plan(p, rank, world_size, &pl)) return rc;
   if (info) {
-    info->n_groups = pl.n_groups; info->n_tiles = pl.n_tiles; info->n_lenses = pl.n_lenses; info->n_promoted = pl.Q;
+    info->n_groups = pl.n_pairs; info->n_tiles = pl.n_tiles; info->n_lenses = pl.n_lenses; info->n_promoted = pl.Q;
     info->n_reduced = pl.n_red_canon; info->max_group_obs = pl.max_group_obs; info->n_chunks = pl.n_blocks; info->max_window_frames = pl.bw + 1;
     info->n_tiles = pl.n_tiles + 4 * pl.n_passes;
   }
@@ -440,7 +440,10 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   // LIFCAL_V2_BLOCKS sets the number of workgroups the LDS-window sweep is cut into (default: one per CU)
   const bool enable_v2 = getenv("LIFCAL_DISABLE_V2") == nullptr;
   const uint32_t v2_blocks = getenv("LIFCAL_V2_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("LIFCAL_V2_BLOCKS"))) : 256u;
-  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks);
+  // LIFCAL_GROUP_SPLIT: observations per lane above which a (point, frame) group is cut into several lanes
+  // (0 = never; default: chosen per block by the planner's cost model)
+  const uint32_t split_obs = getenv("LIFCAL_GROUP_SPLIT") ? (uint32_t)std::max(0, atoi(getenv("LIFCAL_GROUP_SPLIT"))) : UINT32_MAX;
+  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs);
   if (rc) { delete h; return rc; }
   h->prob = *p;
   int ndev = 0;
@@ -485,9 +488,10 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
     U(t, L.gid_fr); d.gid_fr = t; U(t, L.slot_gid); d.slot_gid = t; U(t, L.special_owned); d.special_owned = t;
     U(t, L.blk_pass0); d.blk_pass0 = t; U(t, L.blk_flo); d.blk_flo = t; U(t, L.blk_nf); d.blk_nf = t;
     U(t, L.pass_pt0); d.pass_pt0 = t; U(t, L.pass_np); d.pass_np = t; U(t, L.pass_gid0); d.pass_gid0 = t; U(t, L.pass_ng); d.pass_ng = t;
-    U(t, L.v2_points); d.v2_points = t; U(t, L.v2_ptinfo); d.v2_ptinfo = t; U(t, L.v2_slot); d.v2_slot = t; U(t, L.v2_tile_row0); d.v2_tile_row0 = t; U(t, L.v2_lens); d.v2_lens = t; }
+    U(t, L.v2_points); d.v2_points = t; U(t, L.v2_ptinfo); d.v2_ptinfo = t; U(t, L.v2_passpt); d.v2_passpt = t; U(t, L.v2_slot); d.v2_slot = t; U(t, L.v2_tile_row0); d.v2_tile_row0 = t; U(t, L.v2_lens); d.v2_lens = t; }
   { double* t; U(t, L.v2_u); d.v2_u = t; U(t, L.v2_v); d.v2_v = t; }
   { uint32_t *a, *b, *c; U(a, L.v2f_pt); U(b, L.v2f_fr); U(c, L.v2f_cnt);
+    d.v2f_pt = a;
     h->ts2 = TileSet{4 * L.n_passes, d.v2_tile_row0, a, b, c, d.v2_lens, d.v2_u, d.v2_v}; }
   d.n_blocks = L.n_blocks; d.v2_nfmax = std::max(1u, L.max_block_nf); d.n_special = (uint32_t)L.special_owned.size();
   h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax).total * sizeof(double);
@@ -515,7 +519,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   A(h->red_block, h->red_count);
   d.Sband = h->red_block; d.Sarrow = d.Sband + n_band; d.rhsacc = d.Sarrow + n_arrow; d.gB = d.rhsacc + d.n_red; d.hdiag = d.gB + d.n_red; d.scal = d.hdiag + d.n_red;
   A(d.sig_red, d.n_red); A(d.lam_red, d.n_red); A(d.delta_red, d.n_red); A(d.Linv, (size_t)d.F * 36 + 36);
-  A(d.dbg, (size_t)std::max(1u, d.n_blocks) * 8);
+  A(d.dbg, (size_t)std::max(1u, d.n_blocks) * 16);
   A(d.dP, 3 * (size_t)d.P); A(h->ls_buf, 8);
   A(d.step, ST_N); A(h->partial, 8); A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->pts_gather, 3 * (size_t)d.P);
   // Cholesky panel: LDS when it fits (<= 64 KiB by default launch limits), else a global scratch
@@ -583,12 +587,12 @@ int lifcal_ba_comm_init_rccl(lifcal_ba_handle* h, const void* unique_id128) {
 }
 
 #ifdef LIFCAL_STAMPS
-// diagnostic build only: copies the per-block phase cycle counters of the last k_sweep2 launch (8 per block)
+// diagnostic build only: copies the per-block phase cycle counters of the last k_sweep2 launch (16 per block)
 extern "C" int lifcal_ba_debug_stamps(lifcal_ba_handle* h, unsigned long long* out, uint32_t max_blocks) {
   if (!h || !out) return LIFCAL_BA_ERR_INVALID_ARG;
   const uint32_t n = std::min(max_blocks, h->d.n_blocks);
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(out, h->d.dbg, (size_t)n * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, h->d.dbg, (size_t)n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return (int)n;
 }
 #endif
@@ -596,7 +600,7 @@ extern "C" int lifcal_ba_debug_stamps(lifcal_ba_handle* h, unsigned long long* o
 int lifcal_ba_get_info(lifcal_ba_handle* h, lifcal_ba_info* out) {
   if (!h || !out) return LIFCAL_BA_ERR_INVALID_ARG;
   out->n_obs_local = h->plan.n_obs_local; out->n_points_local = (uint32_t)h->plan.owned_points.size();
-  out->n_groups = h->plan.n_groups; out->n_tiles = h->plan.n_tiles; out->n_lenses = h->plan.n_lenses;
+  out->n_groups = h->plan.n_pairs; out->n_tiles = h->plan.n_tiles; out->n_lenses = h->plan.n_lenses;
   out->n_reduced = h->plan.n_red_canon; out->n_promoted = h->plan.Q; out->n_chunks = h->plan.n_blocks; out->max_window_frames = h->d.bw + 1;
   out->n_tiles = h->plan.n_tiles + 4 * h->plan.n_passes;
   out->device_bytes = h->bytes; out->stream = (void*)h->stream;

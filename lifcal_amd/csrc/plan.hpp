@@ -67,11 +67,13 @@ struct Plan {
   // pass   = <= 256 groups / <= 64 points of a block (4 tiles, group g -> wave g%4, lane g/4)
   static constexpr uint32_t NF_MAX = 20, NP_MAX = 64, PASS_GROUPS = 256, ZD_DOUBLES = 8192;
   uint32_t n_blocks = 0, n_passes = 0, max_block_nf = 0;
+  uint32_t n_pairs = 0;                // (point, frame) pairs with observations; n_groups counts LANES (pairs after splitting)
   std::vector<uint32_t> blk_pass0;     // n_blocks+1
   std::vector<uint32_t> blk_flo, blk_nf;
   std::vector<uint32_t> pass_pt0, pass_np, pass_gid0, pass_ng;   // per pass: first entry in v2_points, #points, first gid, #groups
   std::vector<uint32_t> v2_points;     // point ids in processing order
   std::vector<uint32_t> v2_ptinfo;     // per entry of v2_points: first pass-local group | number of groups << 16
+  std::vector<uint32_t> v2_passpt;     // per (pass*64 + k): k-th point of the pass (0-padded): descriptor-free lookup for the factor phase
   std::vector<uint32_t> v2_slot;       // per (pass*256 + wave*64 + lane): cnt | lf<<8 | lp<<16 | rep<<24 ; 0 = idle
   std::vector<uint32_t> v2f_pt, v2f_fr, v2f_cnt;   // the same slots, flat (value-only kernels: cost, statistics)
   std::vector<uint32_t> v2_tile_row0;  // 4*n_passes+1
@@ -104,7 +106,7 @@ inline int plan_validate(const lifcal_ba_problem* p) {
   return 0;
 }
 
-inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl, bool enable_v2 = true, uint32_t target_blocks = 256) {
+inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl, bool enable_v2 = true, uint32_t target_blocks = 256, uint32_t split_obs = UINT32_MAX) {
   if (int rc = plan_validate(p)) return rc;
   if (world < 1 || rank < 0 || rank >= world) return LIFCAL_BA_ERR_INVALID_ARG;
   Plan& L = *pl;
@@ -226,6 +228,99 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   }
   for (const Group& G : groups) if (G.n > 255) special[G.pt] = 1;   // the v2 slot word keeps the group size in 8 bits
 
+  // --- v2 blocks: contiguous ranges of regular points with ~reg_obs/target observations each, window <= NF_MAX ---
+  std::vector<uint32_t> reg;                 // regular points in point order
+  std::vector<size_t> blk_begin;             // block b = reg[blk_begin[b] .. blk_begin[b+1])
+  L.blk_flo.clear(); L.blk_nf.clear(); L.max_block_nf = 0;
+  L.n_obs_v2 = 0;
+  {
+    uint64_t reg_obs = 0;
+    for (uint32_t q : L.owned_points) if (!special[q] && L.pt_nslots[q] > 0) { reg.push_back(q); reg_obs += cnt[q]; }
+    L.n_obs_v2 = (uint32_t)reg_obs;
+    const uint64_t per_block = std::max<uint64_t>(1, (reg_obs + target_blocks - 1) / std::max(1u, target_blocks));
+    size_t i = 0;
+    while (i < reg.size()) {
+      uint32_t flo = UINT32_MAX, fhi = 0; uint64_t obs = 0; size_t j = i;
+      while (j < reg.size()) {
+        const uint32_t q = reg[j];
+        const uint32_t nlo = std::min(flo, first[q]), nhi = std::max(fhi, last[q]);
+        if (j > i && (nhi - nlo + 1 > Plan::NF_MAX || obs >= per_block)) break;
+        flo = nlo; fhi = nhi; obs += cnt[q]; ++j;
+      }
+      blk_begin.push_back(i);
+      L.blk_flo.push_back(flo); L.blk_nf.push_back(fhi - flo + 1);
+      L.max_block_nf = std::max(L.max_block_nf, fhi - flo + 1);
+      i = j;
+    }
+    blk_begin.push_back(reg.size());
+  }
+  auto block_np_cap = [&](size_t b) {
+    // the dense Z matrix of a pass (3 np rows x padded window columns) must fit its LDS budget
+    const uint32_t ncolp = ((6 * L.blk_nf[b] + (uint32_t)L.nc + 1) + 15u) & ~15u;
+    return std::max(1u, std::min<uint32_t>(Plan::NP_MAX, ((Plan::ZD_DOUBLES / (ncolp + 2)) & ~3u) / 3));
+  };
+
+  // --- lanes: a (point, frame) group of a regular point with more than T observations is cut into near-equal parts, one
+  // lane each.  A wave walks max(lane size) observation steps, so this trades a few more lanes (and their block emission)
+  // for fewer idle steps; every consumer (LDS accumulation, W staging, back-substitution) is linear in the per-lane
+  // blocks, so two lanes with the same (point, frame) simply add up.  T is chosen per block from a cost model of
+  // k_sweep2 (cycles measured with the in-kernel stamps at the 1 M-observation point): more lanes can mean one more pass.
+  L.n_pairs = L.n_groups;
+  {
+    std::vector<uint32_t> split_of(L.P, 0);   // 0 = leave the point's groups whole
+    auto parts_of = [](uint32_t n, uint32_t T) { return T ? (n + T - 1) / T : 1u; };
+    for (size_t b = 0; b + 1 < blk_begin.size(); ++b) {
+      const uint32_t np_cap = block_np_cap(b);
+      uint32_t nmax = 0;
+      for (size_t k = blk_begin[b]; k < blk_begin[b + 1]; ++k)
+        for (uint32_t g = L.pt_slot0[reg[k]]; g < L.pt_slot0[reg[k]] + L.pt_nslots[reg[k]]; ++g) nmax = std::max(nmax, groups[g].n);
+      auto model = [&](uint32_t T, bool& ok) {
+        constexpr double C_STEP = 4500.0, C_PASS = 21500.0, C_LANE = 45.0;
+        uint32_t passes = 0, ng = 0, npp = 0, steps = 0; uint64_t lanes = 0;
+        ok = true;
+        for (size_t k = blk_begin[b]; k < blk_begin[b + 1]; ++k) {
+          uint32_t l = 0;
+          for (uint32_t g = L.pt_slot0[reg[k]]; g < L.pt_slot0[reg[k]] + L.pt_nslots[reg[k]]; ++g) {
+            const uint32_t parts = parts_of(groups[g].n, T);
+            l += parts; steps = std::max(steps, (groups[g].n + parts - 1) / parts);
+          }
+          if (l > Plan::PASS_GROUPS / 4) ok = false;     // keep several points per pass
+          if (passes == 0 || npp >= np_cap || ng + l > Plan::PASS_GROUPS) { ++passes; ng = 0; npp = 0; }
+          ng += l; ++npp; lanes += l;
+        }
+        return passes * (C_STEP * steps + C_PASS) + C_LANE * (double)lanes;
+      };
+      uint32_t best_T = 0; bool ok;
+      double best = model(0, ok);
+      if (split_obs == UINT32_MAX) {            // automatic
+        for (uint32_t T = std::min(nmax, 16u); T >= 2; --T) { const double c = model(T, ok); if (ok && c < best) { best = c; best_T = T; } }
+      } else if (split_obs > 0) {
+        model(split_obs, ok); if (ok) best_T = split_obs;
+      }
+      for (size_t k = blk_begin[b]; k < blk_begin[b + 1]; ++k) split_of[reg[k]] = best_T;
+    }
+    std::vector<Group> cut;
+    cut.reserve(groups.size() * 2);
+    for (const Group& G : groups) {
+      const uint32_t parts = parts_of(G.n, split_of[G.pt]);
+      uint32_t s0 = G.s0;
+      for (uint32_t k = 0; k < parts; ++k) {
+        const uint32_t n = G.n / parts + (k < G.n % parts ? 1u : 0u);
+        cut.push_back({G.pt, G.fr, s0, n});
+        s0 += n;
+      }
+    }
+    groups.swap(cut);
+    L.n_groups = (uint32_t)groups.size();
+    L.gid_fr.resize(L.n_groups);
+    L.pt_slot0.assign(L.P, 0); L.pt_nslots.assign(L.P, 0);
+    for (uint32_t g = 0; g < L.n_groups; ++g) {
+      L.gid_fr[g] = groups[g].fr;
+      if (L.pt_nslots[groups[g].pt] == 0) L.pt_slot0[groups[g].pt] = g;
+      L.pt_nslots[groups[g].pt]++;
+    }
+  }
+
   // --- v1 tiles from the special points' groups ---
   std::vector<uint32_t> g1;
   for (uint32_t g = 0; g < L.n_groups; ++g) if (special[groups[g].pt]) g1.push_back(g);
@@ -254,47 +349,29 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     }
   }
 
-  // --- v2 blocks / passes from the regular points (already in point order) ---
-  L.v2_points.clear(); L.v2_ptinfo.clear(); L.blk_pass0.assign(1, 0); L.blk_flo.clear(); L.blk_nf.clear();
+  // --- v2 passes inside each block ---
+  L.v2_points.clear(); L.v2_ptinfo.clear(); L.blk_pass0.assign(1, 0);
   L.pass_pt0.clear(); L.pass_np.clear(); L.pass_gid0.clear(); L.pass_ng.clear();
-  L.n_obs_v2 = 0;
-  {
-    std::vector<uint32_t> reg;
-    uint64_t reg_obs = 0;
-    for (uint32_t q : L.owned_points) if (!special[q] && L.pt_nslots[q] > 0) { reg.push_back(q); reg_obs += cnt[q]; }
-    L.n_obs_v2 = (uint32_t)reg_obs;
-    // blocks: contiguous ranges with ~reg_obs/target observations each, window <= NF_MAX
-    const uint64_t per_block = std::max<uint64_t>(1, (reg_obs + target_blocks - 1) / std::max(1u, target_blocks));
-    size_t i = 0;
-    while (i < reg.size()) {
-      uint32_t flo = UINT32_MAX, fhi = 0; uint64_t obs = 0; size_t j = i;
-      while (j < reg.size()) {
-        const uint32_t q = reg[j];
-        const uint32_t nlo = std::min(flo, first[q]), nhi = std::max(fhi, last[q]);
-        if (j > i && (nhi - nlo + 1 > Plan::NF_MAX || obs >= per_block)) break;
-        flo = nlo; fhi = nhi; obs += cnt[q]; ++j;
-      }
-      L.blk_flo.push_back(flo); L.blk_nf.push_back(fhi - flo + 1);
-      L.max_block_nf = std::max(L.max_block_nf, fhi - flo + 1);
-      // passes inside the block; the dense Z matrix of a pass (3 np rows x padded window columns) must fit its LDS budget
-      const uint32_t ncolp = ((6 * (fhi - flo + 1) + (uint32_t)L.nc + 1) + 15u) & ~15u;
-      const uint32_t np_cap = std::max(1u, std::min<uint32_t>(Plan::NP_MAX, ((Plan::ZD_DOUBLES / (ncolp + 2)) & ~3u) / 3));
-      size_t a = i;
-      while (a < j) {
-        uint32_t ng = 0, np = 0; size_t e = a;
-        // a pass covers one contiguous run of gids (a special point's groups in between end the pass)
-        while (e < j && np < np_cap && ng + L.pt_nslots[reg[e]] <= Plan::PASS_GROUPS &&
-               (e == a || L.pt_slot0[reg[e]] == L.pt_slot0[reg[e - 1]] + L.pt_nslots[reg[e - 1]])) { ng += L.pt_nslots[reg[e]]; ++np; ++e; }
-        L.pass_pt0.push_back((uint32_t)L.v2_points.size()); L.pass_np.push_back(np);
-        L.pass_gid0.push_back(L.pt_slot0[reg[a]]); L.pass_ng.push_back(ng);
-        { uint32_t g0 = 0; for (size_t k = a; k < e; ++k) { L.v2_points.push_back(reg[k]); L.v2_ptinfo.push_back(g0 | (L.pt_nslots[reg[k]] << 16)); g0 += L.pt_nslots[reg[k]]; } }
-        a = e;
-      }
-      L.blk_pass0.push_back((uint32_t)L.pass_pt0.size());
-      i = j;
+  for (size_t b = 0; b + 1 < blk_begin.size(); ++b) {
+    const uint32_t np_cap = block_np_cap(b);
+    const size_t j = blk_begin[b + 1];
+    size_t a = blk_begin[b];
+    while (a < j) {
+      uint32_t ng = 0, np = 0; size_t e = a;
+      // a pass covers one contiguous run of gids (a special point's groups in between end the pass)
+      while (e < j && np < np_cap && ng + L.pt_nslots[reg[e]] <= Plan::PASS_GROUPS &&
+             (e == a || L.pt_slot0[reg[e]] == L.pt_slot0[reg[e - 1]] + L.pt_nslots[reg[e - 1]])) { ng += L.pt_nslots[reg[e]]; ++np; ++e; }
+      L.pass_pt0.push_back((uint32_t)L.v2_points.size()); L.pass_np.push_back(np);
+      L.pass_gid0.push_back(L.pt_slot0[reg[a]]); L.pass_ng.push_back(ng);
+      { uint32_t g0 = 0; for (size_t k = a; k < e; ++k) { L.v2_points.push_back(reg[k]); L.v2_ptinfo.push_back(g0 | (L.pt_nslots[reg[k]] << 16)); g0 += L.pt_nslots[reg[k]]; } }
+      a = e;
     }
+    L.blk_pass0.push_back((uint32_t)L.pass_pt0.size());
   }
   L.n_blocks = (uint32_t)L.blk_flo.size(); L.n_passes = (uint32_t)L.pass_pt0.size();
+  L.v2_passpt.assign((size_t)L.n_passes * Plan::NP_MAX, 0);
+  for (uint32_t ps = 0; ps < L.n_passes; ++ps)
+    for (uint32_t k = 0; k < L.pass_np[ps]; ++k) L.v2_passpt[(size_t)ps * Plan::NP_MAX + k] = L.v2_points[L.pass_pt0[ps] + k];
   L.v2_slot.assign((size_t)L.n_passes * 256, 0);
   L.v2f_pt.assign((size_t)L.n_passes * 256, 0); L.v2f_fr.assign((size_t)L.n_passes * 256, 0); L.v2f_cnt.assign((size_t)L.n_passes * 256, 0);
   L.v2_tile_row0.assign((size_t)L.n_passes * 4 + 1, 0);

@@ -62,6 +62,11 @@ LIFCAL_DEV double wave_sum_dpp(double v) {
   return v;
 }
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for every global load and
+// store in flight (prefetched descriptors, the W rows on their way to HBM); nothing in k_sweep2 reads back what another wave
+// wrote to global memory, so only the LDS counter has to reach zero before the barrier
+LIFCAL_DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 #ifdef LIFCAL_STAMPS
 #define STAMP(i) do { if (tid == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[i] += t_ - st_last; st_last = t_; } } while (0)
 #else
@@ -90,10 +95,26 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
   const uint32_t zs = ncolp + 2;   // row stride of Zd: ncolp is a multiple of 16 doubles (= all rows on one LDS bank), +2 spreads the rows
   const CamConsts c = *d.camc;
 #ifdef LIFCAL_STAMPS
-  unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
+  unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
   if (tid == 0) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); }
 #endif
-  for (uint32_t i = tid; i < lay.off_slab; i += 256) sm[i] = 0.0;
+  // Pass descriptors and per-lane slot words are fetched ONE PASS AHEAD (the chain descriptor -> slot -> point -> coordinates
+  // is three dependent HBM/L2 round trips otherwise, exposed at the top of every pass with one wave per SIMD)
+  const uint32_t ps_begin = d.blk_pass0[b], ps_end = d.blk_pass0[b + 1];
+  uint32_t nx_np = 0, nx_gid0 = 0, nx_si = 0, nx_pt = 0, nx_row0 = 0, nx_row1 = 0, nx_fp = 0;
+  uint32_t vz;   // an opaque per-lane zero: keeps the descriptor loads in VGPRs (as a uniform value the compiler moves them to
+                 // SGPRs with v_readfirstlane right behind the load, i.e. waits a full memory round trip at the top of every pass)
+  asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+  auto fetch_pass = [&](uint32_t q) {
+    nx_np = d.pass_np[q + vz]; nx_gid0 = d.pass_gid0[q + vz];
+    nx_si = d.v2_slot[(size_t)q * 256 + tid]; nx_pt = d.v2f_pt[(size_t)q * 256 + tid];
+    nx_row0 = d.v2_tile_row0[q * 4 + w]; nx_row1 = d.v2_tile_row0[q * 4 + w + 1];
+    nx_fp = d.v2_passpt[(size_t)q * 64 + (tid & 63u)];            // point the thread factors in phase 2 (threads < np)
+  };
+  if (ps_begin < ps_end) fetch_pass(ps_begin);
+  // (the first pass's descriptor chain is in flight while the window is zero-filled)
+  { double2* z2 = reinterpret_cast<double2*>(sm); for (uint32_t i = tid; i < lay.off_slab / 2; i += 256) z2[i] = double2{0.0, 0.0}; }
+  if (tid == 0 && (lay.off_slab & 1u)) sm[lay.off_slab - 1] = 0.0;
   if (tid < 8) misc[tid] = 0.0;
   for (uint32_t cI = tid; cI < ncolp; cI += 256)
     colinfo[cI] = (cI < 6 * nf) ? (unsigned short)(((cI / 6) << 8) | (cI % 6)) : (cI < ncol - 1 ? (unsigned short)(0x8000u | (cI - 6 * nf)) : (unsigned short)0xC000u);
@@ -187,21 +208,27 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) tacc[i][j] = 0.0;
 
-  for (uint32_t ps = d.blk_pass0[b]; ps < d.blk_pass0[b + 1]; ++ps) {
-    const uint32_t np = d.pass_np[ps], pt0 = d.pass_pt0[ps], gid0 = d.pass_gid0[ps];
+  STAMP(14);
+  for (uint32_t ps = ps_begin; ps < ps_end; ++ps) {
+    const uint32_t np = __builtin_amdgcn_readfirstlane(nx_np), gid0 = __builtin_amdgcn_readfirstlane(nx_gid0);
+    const uint32_t si = nx_si, pt = nx_pt, row0 = nx_row0, kmax = nx_row1 - nx_row0;
+    const uint32_t fp = nx_fp;
+    // Jacobi scales for the factor phase: requested now, consumed after the observation loop
+    double fsg0 = 1.0, fsg1 = 1.0, fsg2 = 1.0;
+    if (mode == 0 && tid < np) { fsg0 = d.sigP[3 * (size_t)fp]; fsg1 = d.sigP[3 * (size_t)fp + 1]; fsg2 = d.sigP[3 * (size_t)fp + 2]; }
+    if (ps + 1 < ps_end) fetch_pass(ps + 1);
     const uint32_t krows = (3 * np + 3u) & ~3u;   // K of the product, multiple of 4
+    STAMP(12);
     for (uint32_t i = tid; i < 64 * 12; i += 256) slab[i] = 0.0;
     if (mode == 0) { double2* z2 = reinterpret_cast<double2*>(Zd); for (uint32_t i = tid; i < (krows * zs) / 2; i += 256) z2[i] = double2{0.0, 0.0}; }
-    __syncthreads();
+    STAMP(13);
+    lds_barrier();
     STAMP(0);
     // ---------------- phase 1: observations -> LDS blocks ----------------
     {
-      const uint32_t si = d.v2_slot[(size_t)ps * 256 + w * 64 + lane];
       const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = (si >> 16) & 0xFFu, rep = (si >> 24) % lay.nrep;
       const uint32_t g = lane * 4 + w;
-      const uint32_t tile = ps * 4 + w;
-      const uint32_t row0 = d.v2_tile_row0[tile], kmax = d.v2_tile_row0[tile + 1] - row0;
-      const uint32_t pt = d.v2_points[pt0 + (cnt ? lp : 0)], fr = flo + lf;
+      const uint32_t fr = flo + lf;
       double R[9], Y[3], c0, s0;
       GroupConsts gcn;
       {
@@ -266,6 +293,11 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
           }
         }
       }
+      // The prefetched words are consumed (for the compiler's wait-count bookkeeping) HERE, where the in-order vmcnt is already
+      // past them: otherwise their first real use sits behind the W / U^-1 stores of this pass and turns into s_waitcnt vmcnt(0),
+      // i.e. a wait for HBM write completion at the top of the next pass and in the factor phase.
+      asm volatile("" :: "v"(nx_si), "v"(nx_pt), "v"(nx_fp), "v"(nx_row0), "v"(nx_row1), "v"(nx_np), "v"(nx_gid0));
+      asm volatile("" :: "v"(fsg0), "v"(fsg1), "v"(fsg2));
       STAMP(7);
       if (cnt > 0) {
         const double Am[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
@@ -336,19 +368,19 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #pragma unroll
             for (int j = 0; j < NC; ++j) atomicAdd(zrow + 6 * nf + j, R[i] * C[0][j] + R[3 + i] * C[1][j] + R[6 + i] * C[2][j]);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const double wij = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j]; zrow[6 * lf + j] = wij; gw[i * 6 + j] = wij; }
+            for (int j = 0; j < 3; ++j) { const double wij = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j]; atomicAdd(zrow + 6 * lf + j, wij); gw[i * 6 + j] = wij; }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const double wij = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j]; zrow[6 * lf + 3 + j] = wij; gw[i * 6 + 3 + j] = wij; }
+            for (int j = 0; j < 3; ++j) { const double wij = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j]; atomicAdd(zrow + 6 * lf + 3 + j, wij); gw[i * 6 + 3 + j] = wij; }
           }
         }
       }
     }
     STAMP(6);
-    __syncthreads();
+    lds_barrier();
     STAMP(1);
     // ---------------- phase 2: one thread per point: damp, factor U = L L^T ----------------
     if (tid < np) {
-      const uint32_t p = d.v2_points[pt0 + tid];
+      const uint32_t p = fp;
       pidl[tid] = p;
       double* acc = slab + tid * 12;
       double U0 = acc[0], U1 = acc[1], U2 = acc[2], U3 = acc[3], U4 = acc[4], U5 = acc[5];
@@ -359,18 +391,20 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
         const double g0 = acc[6], g1 = acc[7], g2 = acc[8];
         double lam[3];
         {
-          const double h[3] = {U0, U3, U5};
+          const double h[3] = {U0, U3, U5}, sgv[3] = {fsg0, fsg1, fsg2};
 #pragma unroll
-          for (int k = 0; k < 3; ++k) { const double sg = d.sigP[3 * (size_t)p + k]; lam[k] = fmin(fmax(h[k] * sg * sg, d.lm_min), d.lm_max) / (radius * sg * sg); }
+          for (int k = 0; k < 3; ++k) { const double sg = sgv[k]; lam[k] = fmin(fmax(h[k] * sg * sg, d.lm_min), d.lm_max) / (radius * sg * sg); }
         }
         U0 += lam[0]; U3 += lam[1]; U5 += lam[2];
-        bool ok = true;
-        double l00 = U0; ok = ok && (l00 > 0.0); l00 = sqrt(l00);
-        const double l10 = U1 / l00, l20 = U2 / l00;
-        double l11 = U3 - l10 * l10; ok = ok && (l11 > 0.0); l11 = sqrt(l11);
-        const double l21 = (U4 - l20 * l10) / l11;
-        double l22 = U5 - l20 * l20 - l21 * l21; ok = ok && (l22 > 0.0); l22 = sqrt(l22);
-        double i00 = 1.0 / l00, i11 = 1.0 / l11, i22 = 1.0 / l22;
+        // L^-1 of the 3x3 Cholesky factor through reciprocal square roots (one wave, a pure latency chain: no sqrt + divide pairs)
+        bool ok = U0 > 0.0;
+        double i00 = rsqrt(U0);
+        const double l10 = U1 * i00, l20 = U2 * i00;
+        const double d11 = U3 - l10 * l10; ok = ok && (d11 > 0.0);
+        double i11 = rsqrt(d11);
+        const double l21 = (U4 - l20 * l10) * i11;
+        const double d22 = U5 - l20 * l20 - l21 * l21; ok = ok && (d22 > 0.0);
+        double i22 = rsqrt(d22);
         double m10 = -l10 * i00 * i11, m21 = -l21 * i11 * i22, m20 = -(l20 * i00 + l21 * m10) * i22;
         if (!ok) { i00 = i11 = i22 = m10 = m21 = m20 = 0.0; atomicAdd(misc + 1, 1.0); }
         double* gu = d.Uinv + 9 * (size_t)p;
@@ -388,7 +422,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
         z0[0] = i00 * g0; z0[zs] = m10 * g0 + i11 * g1; z0[2 * zs] = m20 * g0 + m21 * g1 + i22 * g2;
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(2);
     if (mode == 0) {
       // ---------------- phase 3: camera part of W -> HBM, then Z = L^-1 W in place (pose + camera columns) ----------------
@@ -398,6 +432,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
       const uint32_t gi = tid / nwc, cidx = tid - gi * nwc;
       if (gi < nth || nwc > 256) {
         for (uint32_t cc0 = cidx; cc0 < nwc; cc0 += (nwc > 256 ? 256 : nwc * nth)) {
+#pragma unroll 4
           for (uint32_t lp = (nwc > 256 ? 0 : gi); lp < np; lp += (nwc > 256 ? 1 : nth)) {
             const double* acc = slab + lp * 12;
             double* z = Zd + (size_t)(3 * lp) * zs + cc0;
@@ -410,7 +445,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
           }
         }
       }
-      __syncthreads();
+      lds_barrier();
       STAMP(3);
       // ---------------- phase 4: window -= Zd^T Zd on the f64 matrix cores, one 16x16 output tile per wave at a time ----------------
       // Register-blocked fp64 product on the vector ALUs: measured on gfx950, v_fmac_f64 (6.3 cycles per wave
@@ -431,13 +466,16 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(4);
   }
+  STAMP(8);
   if (keep_tiles && tid < ntri) emit_tile(mi0, mj0, tacc);   // (colinfo and the window are only read/written by owners: no barrier needed before)
+  STAMP(9);
   if (d.robust) cost += 0.5 * c.loss_b * (log(lmant) + (double)lexp * 0.6931471805599453);
   // ---------------- camera x camera block, camera gradient, cost: 256-way reduction through LDS ----------------
   // every thread parks its partial sums as [value][thread] in the (now free) Zd region, 8 threads per value add them up
+  // (row stride 264 and interleaved parts: the 32 lanes of one ds_read_b64 group touch 32 distinct bank pairs)
   {
     constexpr int NV = NCC + NC + 1, RV = 28;   // 28 values x 256 threads x 8 B = 56 KiB per round
 #pragma unroll
@@ -445,14 +483,15 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #pragma unroll
       for (int v = 0; v < RV; ++v) {
         const int idx = round * RV + v;
-        if (idx < NV) Zd[v * 256 + tid] = (idx < NCC) ? cc[idx < NCC ? idx : 0] : (idx < NCC + NC ? gc[(idx - NCC) >= 0 && (idx - NCC) < NC ? idx - NCC : 0] : cost);
+        if (idx < NV) Zd[v * 264 + tid] = (idx < NCC) ? cc[idx < NCC ? idx : 0] : (idx < NCC + NC ? gc[(idx - NCC) >= 0 && (idx - NCC) < NC ? idx - NCC : 0] : cost);
       }
       __syncthreads();
       if (tid < RV * 8) {
         const int v = tid >> 3, part = tid & 7, idx = round * RV + v;
         if (idx < NV) {
           double sacc = 0.0;
-          for (int k = 0; k < 32; ++k) sacc += Zd[v * 256 + part * 32 + k];
+#pragma unroll 8
+          for (int k = 0; k < 32; ++k) sacc += Zd[v * 264 + part + 8 * k];
           if (idx < NCC) {
             int i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i;
             if (mode == 0) atomicAdd(Scc + idx, sacc);
@@ -468,6 +507,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     }
   }
   __syncthreads();
+  STAMP(10);
   // fold the replicas: pose x pose diagonal blocks (+ Hessian diagonal), pose gradient, camera x pose
   for (uint32_t i = tid; i < FRV * nf; i += 256) {
     const uint32_t v = i / nf, lf = i % nf;
@@ -486,7 +526,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     }
   }
   __syncthreads();
-  STAMP(5);
+  STAMP(11);
   // ---------------- flush the window into the global reduced system (contiguous runs) ----------------
   const uint32_t F6 = 6 * d.F, camrow = 3 * d.Q, camcol = F6 + 3 * d.Q;
   for (uint32_t i = tid; i < 6 * nf; i += 256) atomicAdd(d.hdiag + 6 * flo + i, vhd[i]);
@@ -522,7 +562,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #ifdef LIFCAL_STAMPS
   __syncthreads();
   STAMP(5);
-  if (tid == 0 && d.dbg) for (int i = 0; i < 8; ++i) d.dbg[(size_t)b * 8 + i] = st_acc[i];
+  if (tid == 0 && d.dbg) for (int i = 0; i < 16; ++i) d.dbg[(size_t)b * 16 + i] = st_acc[i];
 #endif
 }
 
