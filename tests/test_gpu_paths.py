@@ -59,6 +59,19 @@ def test_block_count_does_not_change_the_result(built, tmp_path, blocks):
     assert scaled_max_err(a["S"], b["S"]) < 1e-10 and vec_err(a["rhs"], b["rhs"]) < 1e-10
 
 
+@pytest.mark.parametrize("split", ["0", "1", "2", "3", "6"])
+def test_group_splitting_does_not_change_the_result(built, tmp_path, split):
+    """LIFCAL_GROUP_SPLIT cuts (point, frame) groups into several lanes of at most that many observations; the per-lane
+    blocks add up, so the reduced system, the point gradients and U^-1 must not move (1 = one observation per lane)"""
+    spec_args = "30, 300, 8, 0xF06, 1206, outlier_fraction=0.02"
+    a = run_child(tmp_path, spec_args, {"LIFCAL_GROUP_SPLIT": split}, "s" + split)
+    b = run_child(tmp_path, spec_args, {"LIFCAL_DISABLE_V2": "1"}, "ref")
+    assert int(a["chunks"]) >= 1
+    assert abs(float(a["cost"]) - float(b["cost"])) <= 1e-13 * float(b["cost"])
+    assert scaled_max_err(a["S"], b["S"]) < 1e-10 and vec_err(a["rhs"], b["rhs"]) < 1e-10
+    assert vec_err(a["pg"], b["pg"]) < 1e-11 and vec_err(a["ui"], b["ui"]) < 1e-10
+
+
 def test_mixed_regular_and_oversized_points(built):
     """a few points are also seen 25 frames later (span > 20 frame window): they take the fallback path, the rest v2"""
     sc = scene.make_scene(S(40, 300, 8, 0xF06, 1205, outlier_fraction=0.02))
