@@ -1,0 +1,65 @@
+"""BASELINE.json configs[3] and configs[4] at FULL size on one GPU (fp64 arms).
+
+configs[3]: 1000 frames, 50 k points (~2.4 M micro-image observations with this MLA), 0xF06 — the problem the 8-GPU run
+shards; here the whole of it on one device.  configs[4]: recalib mode, 2000 frames, 100 k points (~4.8 M observations):
+the reference's recalibration arm (camera slots {0,2} constant + box bounds 0.7/1.3 on slots 1,3,4, reference
+src/CameraCalibration.cpp:927-952) and the BASELINE arm "intrinsics fixed, pose+point refine".
+The oracle is too slow to form the Schur complement at these sizes, so the comparators are its cheap parts (cost,
+reprojection statistics, both O(N) and threaded) and size-independent properties of the solve."""
+import numpy as np
+import pytest
+
+import oracle
+from lifcal_amd import BundleAdjustment, _capi as capi, scene
+from tests.helpers import problem
+
+pytestmark = pytest.mark.gpu
+
+
+def check_solve(pa, fixed=(), lower=None, upper=None):
+    cam0 = pa.cam.copy()
+    threads = oracle.hardware_threads()
+    c0 = oracle.cost(pa, threads=threads)
+    with BundleAdjustment(pa) as ba:
+        first = ba.sweep(1e4)
+        assert abs(first.cost - c0) <= 1e-11 * c0                      # same objective at the start
+        again = ba.sweep(1e4)
+        assert abs(again.cost - first.cost) <= 1e-11 * first.cost      # idempotent up to summation order
+        s = ba.performBundleAdjustment()
+        st = ba.calcReprojectionError()
+        end = ba.sweep(s.final_radius)
+    assert s.termination in (1, 2), s.termination
+    assert s.final_cost < 0.2 * s.initial_cost
+    assert abs(end.cost - s.final_cost) <= 1e-9 * s.final_cost         # device-resident point == reported point
+    c1 = oracle.cost(pa, threads=threads)                              # ... == the point written back to the caller
+    assert abs(c1 - s.final_cost) <= 1e-9 * s.final_cost
+    so = oracle.reproj_stats(pa)
+    assert abs(st.std_x - so.std_x) < 1e-9 and abs(st.std_y - so.std_y) < 1e-9 and st.num_inliers == so.num_inliers
+    assert st.std_x < 1.0 and st.std_y < 1.0 and st.num_inliers > 0.95 * st.num_points    # 2 % outliers at +-5 px
+    for j in fixed:
+        assert pa.cam[j] == cam0[j]                                    # constant slots come back bit-identical
+    if lower is not None:
+        assert np.all(pa.cam >= lower) and np.all(pa.cam <= upper)
+    return s, st
+
+
+def test_cfg4_whole_problem_on_one_gpu(built):
+    sc = scene.make_scene(scene.baseline_spec("cfg4"))
+    assert sc.spec.n_frames == 1000 and sc.spec.n_points == 50000 and sc.n_obs > 2_000_000
+    pa = problem(sc)
+    s, st = check_solve(pa)
+    # the truth is known: intrinsics come back to the generator's values (gauge-free quantities) within the noise
+    assert abs(pa.cam[0] - sc.spec.fL) < 2e-2 * sc.spec.fL and abs(pa.cam[2] - sc.spec.B) < 2e-2 * sc.spec.B
+
+
+def test_cfg5_recalibration_arms(built):
+    sc = scene.make_scene(scene.baseline_spec("cfg5"))
+    assert sc.spec.n_frames == 2000 and sc.fixed_mask == 0b101 and sc.lower is not None
+    # arm 1: the reference's recalibration set-up (slots 0 and 2 constant, bounds on 1, 3, 4)
+    pa = problem(sc)
+    check_solve(pa, fixed=(0, 2), lower=sc.lower, upper=sc.upper)
+    # arm 2: BASELINE wording — every intrinsic constant (at its calibrated value), poses and points refined
+    live = 5 + (sc.config & 3) + (2 if sc.config & 4 else 0)
+    pa2 = capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, sc.cam_gt.copy(), sc.views0.copy(), sc.pts0.copy(),
+                             sc.spx, sc.scale, sc.config, fixed_mask=(1 << live) - 1)
+    check_solve(pa2, fixed=tuple(range(live)))
