@@ -30,8 +30,8 @@ import numpy as np  # noqa: E402
 HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md
 FP64_PEAK = 78.6e12  # flop/s, fp64 vector peak (256 CU x 4 SIMD x 16 lanes x 2 x 2.4 GHz)
 # fp64 flops the sweep EXECUTES per observation at the metric point (config 0xF06), counted in the gfx950 ISA / kernel
-# source: observation loop 689 + block emission ~155 + Schur product ~570 + factor/Z ~35
-FP64_FLOP_PER_OBS = 1450.0
+# source: observation loop ~600 + block emission ~155 + Schur product ~570 + factor/Z ~35
+FP64_FLOP_PER_OBS = 1360.0
 
 
 def tiled_problem(sc, copies):

@@ -249,4 +249,90 @@ LIFCAL_DEV void obs_eval(const CamConsts& c, const GroupConsts& g, const double*
   for (int j = 0; j < NC; ++j) { Jc[0][j] = dx[j] * c.isp[0] * c.chm[j]; Jc[1][j] = dy[j] * c.isp[1] * c.chm[j]; }
 }
 
+
+// ---- lean variant for the LDS-window kernel (k_sweep2) ----
+// Same mathematics as obs_eval, three per-observation savings:
+//   * d pMl/d(fL,bL0,B) = q kq + c_u kc with kc = a kw + (mu+1) da folded per group (ADJ),
+//   * d pMl/d(lens parameter) = gl * tangent with gl = (mu+1) a folded per group,
+//   * the pixel scale 1/sp and the robust weight sqrt(rho') go into ONE pair of row factors; the sign/scale folding chm[j]
+//     is NOT applied: Jc comes back in model-parameter columns and the caller scales its accumulated blocks once.
+struct GroupConsts2 {
+  double X, Y, iZq, gz;
+  double kq[3], kc[3];   // ADJ: dx[i] = q kq[i] + c_u kc[i];  !ADJ: kc = kw (multiplies w = c_u)
+  double gl;             // ADJ: (mu + 1) a;  !ADJ: mu
+};
+
+template <bool ADJ>
+LIFCAL_DEV void group_prepare2(const CamConsts& c, double X, double Y, double Z, GroupConsts2& g) {
+  g.X = X; g.Y = Y; g.iZq = 1.0 / (Z + c.zC0);
+  g.gz = c.gamma * g.iZq;
+  const double mu = g.gz * c.e - c.beta;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    g.kq[i] = c.dgamma[i] - g.gz * c.dzC0[i];
+    const double kw = g.gz * c.de[i] - c.dbeta[i];
+    g.kc[i] = ADJ ? c.a * kw + (mu + 1.0) * c.da[i] : kw;
+  }
+  g.gl = ADJ ? (mu + 1.0) * c.a : mu;
+}
+
+// returns the Cauchy argument 1 + s/b (robust) or the squared residual norm (not robust) through `arg`;
+// r, Jq, Jc come back already multiplied by sqrt(rho') when robust
+template <int NR, bool TAN, bool ADJ>
+LIFCAL_DEV void obs_eval2(const CamConsts& c, const GroupConsts2& g, const double* __restrict__ L, double u, double v, bool robust,
+                          double r[2], double Jq[2][3], double Jc[2][5 + NR + (TAN ? 2 : 0)], double& arg) {
+  constexpr int NA = 2 + NR + (TAN ? 2 : 0);
+  constexpr int NC = 3 + NA;
+  const double mx = L[0], my = L[1], cux = L[2], cuy = L[3];
+  const double wx = ADJ ? cux * c.a : cux, wy = ADJ ? cuy * c.a : cuy;
+  const double qx = (g.X + wx * c.e) * g.iZq, qy = (g.Y + wy * c.e) * g.iZq;
+  const double mlx = c.gamma * qx - c.beta * wx, mly = c.gamma * qy - c.beta * wy;
+  double dx[NC], dy[NC];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { dx[i] = qx * g.kq[i] + cux * g.kc[i]; dy[i] = qy * g.kq[i] + cuy * g.kc[i]; }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) { dx[3 + a] = g.gl * L[4 + 2 * a]; dy[3 + a] = g.gl * L[5 + 2 * a]; }
+  const double qxZ = -g.gz * qx, qyZ = -g.gz * qy;
+  double px, py;
+  double j00, j01, j02, j10, j11, j12;  // d proj / d (X,Y,Z)
+  if (ADJ) {
+    px = mlx + wx; py = mly + wy;
+    if (NR > 0 || TAN) {
+      Distortion<NR, TAN> d; d.eval(px, py, c, true);
+      const double b00 = 1.0 + d.A00, b01 = d.A01, b10 = d.A10, b11 = 1.0 + d.A11;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        double ex = 0.0, ey = 0.0;
+        if (i >= 3) d.explicit_partial(i - 3, px, py, ex, ey);
+        const double nx = b00 * dx[i] + b01 * dy[i] + ex, ny = b10 * dx[i] + b11 * dy[i] + ey;
+        dx[i] = nx; dy[i] = ny;
+      }
+      j00 = b00 * g.gz; j01 = b01 * g.gz; j02 = b00 * qxZ + b01 * qyZ;
+      j10 = b10 * g.gz; j11 = b11 * g.gz; j12 = b10 * qxZ + b11 * qyZ;
+      px += d.dx; py += d.dy;
+    } else {
+      j00 = g.gz; j01 = 0.0; j02 = qxZ; j10 = 0.0; j11 = g.gz; j12 = qyZ;
+    }
+    dx[3] += c.sp[0]; dy[4] += c.sp[1];
+  } else {
+    px = mlx + (mx - c.craw[0]) * c.sp[0]; py = mly + (my - c.craw[1]) * c.sp[1];
+    j00 = g.gz; j01 = 0.0; j02 = qxZ; j10 = 0.0; j11 = g.gz; j12 = qyZ;
+  }
+  r[0] = px * c.isp[0] + c.craw[0] - u;
+  r[1] = py * c.isp[1] + c.craw[1] - v;
+  const double sq = r[0] * r[0] + r[1] * r[1];
+  double s0 = c.isp[0], s1 = c.isp[1];
+  if (robust) {   // ceres::CauchyLoss + Corrector with rho'' < 0: r and J scaled by sqrt(rho') = rsqrt(1 + s/b)
+    arg = 1.0 + sq * c.loss_c;
+    const double sc = rsqrt(arg);
+    r[0] *= sc; r[1] *= sc; s0 *= sc; s1 *= sc;
+  } else {
+    arg = sq;
+  }
+  Jq[0][0] = j00 * s0; Jq[0][1] = j01 * s0; Jq[0][2] = j02 * s0;
+  Jq[1][0] = j10 * s1; Jq[1][1] = j11 * s1; Jq[1][2] = j12 * s1;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) { Jc[0][j] = dx[j] * s0; Jc[1][j] = dy[j] * s1; }
+}
+
 }  // namespace lifcal

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
       const uint32_t g = lane * 4 + w;
       const uint32_t fr = flo + lf;
       double R[9], Y[3], c0, s0;
-      GroupConsts gcn;
+      GroupConsts2 gcn;
       {
         const double* ft = d.ft + (size_t)fr * FRAME_STRIDE;
         const double* P = d.pts + 3 * (size_t)pt;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #pragma unroll
         for (int k = 0; k < 3; ++k) Y[k] = R[3 * k] * P0 + R[3 * k + 1] * P1 + R[3 * k + 2] * P2;
         c0 = ft[12]; s0 = ft[13];
-        group_prepare(c, Y[0] + ft[9], Y[1] + ft[10], Y[2] + ft[11], gcn);
+        group_prepare2<ADJ>(c, Y[0] + ft[9], Y[1] + ft[10], Y[2] + ft[11], gcn);
       }
       double A[6] = {0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0}, C[3][NC];
 #pragma unroll
@@ -254,24 +254,14 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
           const double u = d.v2_u[at], v = d.v2_v[at];
           const double* L = d.lt + (size_t)d.v2_lens[at] * LENS_STRIDE;
           double r[2], Jq[2][3], Jc[2][NC];
-          obs_eval<NR, TAN, ADJ>(c, gcn, L, u, v, r, Jq, Jc);
-          const double sq = r[0] * r[0] + r[1] * r[1];
-          if (d.robust) {  // ceres::CauchyLoss + Corrector with rho'' < 0: scale r and J by sqrt(rho')
-            // rho = b log(1 + s/b): the lane keeps the running PRODUCT of (1 + s/b) as mantissa x 2^exponent and takes one
-            // log at the end; sqrt(rho') = rsqrt(1 + s/b)
-            const double sum = 1.0 + sq * c.loss_c;
-            int ex; lmant = frexp(lmant * sum, &ex); lexp += ex;
-            const double sc = rsqrt(sum);
-            r[0] *= sc; r[1] *= sc;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-#pragma unroll
-              for (int j = 0; j < 3; ++j) Jq[a][j] *= sc;
-#pragma unroll
-              for (int j = 0; j < NC; ++j) Jc[a][j] *= sc;
-            }
+          double arg;
+          obs_eval2<NR, TAN, ADJ>(c, gcn, L, u, v, d.robust != 0, r, Jq, Jc, arg);
+          if (d.robust) {
+            // rho = b log(1 + s/b): the lane keeps the running PRODUCT of the arguments as mantissa x 2^exponent and takes
+            // one log at the end
+            int ex; lmant = frexp(lmant * arg, &ex); lexp += ex;
           } else {
-            cost += 0.5 * sq;
+            cost += 0.5 * arg;
           }
 #pragma unroll
           for (int a = 0; a < 2; ++a) {
@@ -300,6 +290,11 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
       asm volatile("" :: "v"(fsg0), "v"(fsg1), "v"(fsg2));
       STAMP(7);
       if (cnt > 0) {
+        // Jc came back in model-parameter columns: sign/scale folding and the free-column mask, once per group
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < NC; ++j) C[i][j] *= c.chm[j];
         const double Am[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
         // Gr = [e_x x Y, (0,c0,s0) x Y, R[:,2] x Y]: d(R P)/d(a0,a1,a2)
         const double n0 = R[2], n1 = R[5], n2 = R[8];
@@ -472,6 +467,15 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
   STAMP(8);
   if (keep_tiles && tid < ntri) emit_tile(mi0, mj0, tacc);   // (colinfo and the window are only read/written by owners: no barrier needed before)
   STAMP(9);
+  {  // the same folding for the lane's camera x camera block and camera gradient
+    int t = 0;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+      gc[i] *= c.chm[i];
+#pragma unroll
+      for (int j = 0; j <= i; ++j) cc[t++] *= c.chm[i] * c.chm[j];
+    }
+  }
   if (d.robust) cost += 0.5 * c.loss_b * (log(lmant) + (double)lexp * 0.6931471805599453);
   // ---------------- camera x camera block, camera gradient, cost: 256-way reduction through LDS ----------------
   // every thread parks its partial sums as [value][thread] in the (now free) Zd region, 8 threads per value add them up
