@@ -158,6 +158,17 @@ def main():
             hip.hipMemcpy(ptr, buf.ctypes.data, count * 8, 1)
             return 0
         ba.set_allreduce(hook)
+
+        def ghook(send, recv, count, stream):
+            hip.hipStreamSynchronize(stream)
+            buf = np.empty(count)
+            hip.hipMemcpy(buf.ctypes.data, send, count * 8, 2)
+            parts = [torch.empty(count, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(parts, torch.from_numpy(buf))
+            allb = torch.cat(parts).numpy()
+            hip.hipMemcpy(recv, allb.ctypes.data, world * count * 8, 1)
+            return 0
+        ba.set_allgather(ghook)
     info = ba.info()
     radius = 1e4
 

@@ -165,6 +165,13 @@ typedef struct lifcal_ba_handle lifcal_ba_handle;
  * RCCL communicator (lifcal_ba_comm_init_rccl).  `stream` is the hipStream_t the buffer was
  * produced on; the hook must leave the reduced result in place, ordered on that stream. */
 typedef int (*lifcal_ba_allreduce_fn)(void* ctx, void* device_buf, size_t count_f64, void* stream);
+/* Optional second collective.  Points are owned in first-frame order, so the partial reduced system of a rank is
+ * non-zero only in ONE contiguous range of frames (+ the small camera block): instead of summing the whole block the
+ * library packs that range into a slab, ALL-GATHERS the equally sized slabs (count_f64 doubles per rank; recv holds
+ * world_size * count_f64, rank-major) and adds them up locally - about half the bytes of the all-reduce, and it is the
+ * path the library-owned RCCL communicator takes by itself.  With hooks it is used when BOTH hooks are installed (the
+ * all-reduce is still needed for a few small buffers); LIFCAL_DENSE_ALLREDUCE=1 forces the plain all-reduce. */
+typedef int (*lifcal_ba_allgather_fn)(void* ctx, const void* device_send, void* device_recv, size_t count_f64, void* stream);
 
 void lifcal_ba_default_options(lifcal_ba_options* o);
 
@@ -203,6 +210,7 @@ int lifcal_ba_upload_parameters(lifcal_ba_handle* h);
 int lifcal_ba_download_parameters(lifcal_ba_handle* h);
 
 int lifcal_ba_set_allreduce(lifcal_ba_handle* h, lifcal_ba_allreduce_fn fn, void* ctx);
+int lifcal_ba_set_allgather(lifcal_ba_handle* h, lifcal_ba_allgather_fn fn, void* ctx);
 /* RCCL path: rank 0 calls unique_id (128 bytes), distributes it, every rank calls init */
 int lifcal_ba_comm_unique_id(void* out128);
 int lifcal_ba_comm_init_rccl(lifcal_ba_handle* h, const void* unique_id128);

@@ -80,6 +80,7 @@ class PlanInfo(C.Structure):
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
 # every symbol include/lifcal_ba.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
@@ -94,6 +95,7 @@ PROTOTYPES = {
     "lifcal_ba_upload_parameters": (C.c_int, [C.c_void_p]),
     "lifcal_ba_download_parameters": (C.c_int, [C.c_void_p]),
     "lifcal_ba_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
+    "lifcal_ba_set_allgather": (C.c_int, [C.c_void_p, ALLGATHER_FN, C.c_void_p]),
     "lifcal_ba_comm_unique_id": (C.c_int, [C.c_void_p]),
     "lifcal_ba_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lifcal_ba_get_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),

@@ -144,6 +144,18 @@ class BundleAdjustment:
         self._hook = capi.ALLREDUCE_FN(tramp)
         _check(self.lib, self.lib.lifcal_ba_set_allreduce(self._h, self._hook, None), "lifcal_ba_set_allreduce")
 
+    def set_allgather(self, fn):
+        """fn(send_ptr:int, recv_ptr:int, count_per_rank:int, stream:int) -> 0 on success; recv is rank-major."""
+        def tramp(ctx, send, recv, count, stream):
+            try:
+                return int(fn(int(send or 0), int(recv or 0), int(count), int(stream or 0)))
+            except Exception:  # never let an exception cross the C boundary
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._ghook = capi.ALLGATHER_FN(tramp)
+        _check(self.lib, self.lib.lifcal_ba_set_allgather(self._h, self._ghook, None), "lifcal_ba_set_allgather")
+
     def comm_init_rccl(self, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)
         _check(self.lib, self.lib.lifcal_ba_comm_init_rccl(self._h, buf), "lifcal_ba_comm_init_rccl")

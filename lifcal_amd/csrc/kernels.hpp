@@ -545,6 +545,80 @@ __global__ __launch_bounds__(256) void k_schur(Dev d, double radius) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// multi-GPU exchange of the reduced block as frame slabs (see lifcal_ba_allgather_fn in include/lifcal_ba.h)
+// slab of one rank: band [maxn][BS] | camera x pose [maxn][NA][6] | rhsacc,gB,hdiag [maxn][3][6] |
+//                   tail: arrow x arrow [NA][NA] | camera entries of the three vectors [3][NA] | scal[SCAL_N]
+// (only used when no point is promoted: the arrow rows are then the NA = nc camera rows)
+// ---------------------------------------------------------------------------------------------
+struct Xch {
+  uint32_t world, rank, maxn, BS, NA, F6;
+  uint32_t off_arrow, off_vec, off_tail, SL;
+  const uint32_t *flo, *nfr;   // per rank
+  double* send; const double* recv;
+};
+
+__global__ void k_xch_pack(Dev d, Xch x) {
+  const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= x.SL) return;
+  const uint32_t flo = x.flo[x.rank], n = x.nfr[x.rank];
+  double v = 0.0;
+  if (s < x.off_arrow) {
+    const uint32_t fl = s / x.BS, e = s - fl * x.BS;
+    if (fl >= n) return;
+    v = d.Sband[(size_t)(flo + fl) * x.BS + e];
+  } else if (s < x.off_vec) {
+    const uint32_t t = s - x.off_arrow, fl = t / (x.NA * 6), j = (t / 6) % x.NA, k = t % 6;
+    if (fl >= n) return;
+    v = d.Sarrow[(size_t)j * d.ld + 6 * (flo + fl) + k];
+  } else if (s < x.off_tail) {
+    const uint32_t t = s - x.off_vec, fl = t / 18, w = (t / 6) % 3, k = t % 6;
+    if (fl >= n) return;
+    const double* src = w == 0 ? d.rhsacc : (w == 1 ? d.gB : d.hdiag);
+    v = src[6 * (flo + fl) + k];
+  } else {
+    const uint32_t t = s - x.off_tail;
+    if (t < x.NA * x.NA) v = d.Sarrow[(size_t)(t / x.NA) * d.ld + x.F6 + t % x.NA];
+    else if (t < x.NA * x.NA + 3 * x.NA) { const uint32_t q = t - x.NA * x.NA, w = q / x.NA; const double* src = w == 0 ? d.rhsacc : (w == 1 ? d.gB : d.hdiag); v = src[x.F6 + q % x.NA]; }
+    else v = d.scal[t - x.NA * x.NA - 3 * x.NA];
+  }
+  x.send[s] = v;
+}
+
+// one thread per entry of the reduced block: sum of the slabs that cover its frame (every entry is rewritten)
+__global__ void k_xch_unpack(Dev d, Xch x) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t nB = (size_t)(x.F6 / 6) * x.BS, nA = (size_t)x.NA * x.F6, nV = (size_t)3 * x.F6;
+  const uint32_t nT = x.NA * x.NA + 3 * x.NA + SCAL_N;
+  if (i >= nB + nA + nV + nT) return;
+  double sum = 0.0;
+  double* dst;
+  if (i < nB + nA + nV) {
+    uint32_t f, within;   // frame of the entry, offset of the entry inside a slab relative to the frame's record
+    size_t base;          // start of the piece inside a slab
+    uint32_t rec;         // record length per frame in that piece
+    if (i < nB) { f = (uint32_t)(i / x.BS); within = (uint32_t)(i - (size_t)f * x.BS); base = 0; rec = x.BS; dst = d.Sband + i; }
+    else if (i < nB + nA) {
+      const size_t t = i - nB; const uint32_t j = (uint32_t)(t / x.F6), col = (uint32_t)(t - (size_t)j * x.F6);
+      f = col / 6; within = j * 6 + col % 6; base = x.off_arrow; rec = x.NA * 6; dst = d.Sarrow + (size_t)j * d.ld + col;
+    } else {
+      const size_t t = i - nB - nA; const uint32_t w = (uint32_t)(t / x.F6), col = (uint32_t)(t - (size_t)w * x.F6);
+      f = col / 6; within = w * 6 + col % 6; base = x.off_vec; rec = 18; dst = (w == 0 ? d.rhsacc : (w == 1 ? d.gB : d.hdiag)) + col;
+    }
+    for (uint32_t r = 0; r < x.world; ++r) {
+      const uint32_t fl = f - x.flo[r];   // wraps for f < flo: fails the range test
+      if (fl < x.nfr[r]) sum += x.recv[(size_t)r * x.SL + base + (size_t)fl * rec + within];
+    }
+  } else {
+    const uint32_t t = (uint32_t)(i - nB - nA - nV);
+    for (uint32_t r = 0; r < x.world; ++r) sum += x.recv[(size_t)r * x.SL + x.off_tail + t];
+    if (t < x.NA * x.NA) dst = d.Sarrow + (size_t)(t / x.NA) * d.ld + x.F6 + t % x.NA;
+    else if (t < x.NA * x.NA + 3 * x.NA) { const uint32_t q = t - x.NA * x.NA, w = q / x.NA; dst = (w == 0 ? d.rhsacc : (w == 1 ? d.gB : d.hdiag)) + x.F6 + q % x.NA; }
+    else dst = d.scal + (t - x.NA * x.NA - 3 * x.NA);
+  }
+  *dst = sum;
+}
+
+// ---------------------------------------------------------------------------------------------
 // finalize: LM diagonal on the reduced system + rhs row; identity on columns that are not solved for
 // ---------------------------------------------------------------------------------------------
 __global__ void k_finalize(Dev d, double radius) {

@@ -49,6 +49,7 @@ struct Rccl {
   int (*GetUniqueId)(NcclUniqueId*) = nullptr;
   int (*CommInitRank)(void**, int, NcclUniqueId, int) = nullptr;
   int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   bool load() {
     if (lib) return true;
@@ -58,8 +59,9 @@ struct Rccl {
     GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
     CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
     AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+    AllGather = (decltype(AllGather))dlsym(lib, "ncclAllGather");
     CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
-    return GetUniqueId && CommInitRank && AllReduce && CommDestroy;
+    return GetUniqueId && CommInitRank && AllReduce && AllGather && CommDestroy;
   }
 };
 Rccl g_rccl;
@@ -89,6 +91,8 @@ struct lifcal_ba_handle {
   bool sigma_valid = false;
   bool constrained = false;
   lifcal_ba_allreduce_fn hook = nullptr; void* hook_ctx = nullptr;
+  lifcal_ba_allgather_fn ghook = nullptr; void* ghook_ctx = nullptr;
+  Xch xch{}; bool xch_ok = false;   // slab exchange of the reduced block (multi-GPU, no promoted points)
   void* comm = nullptr;
   double last_cost = 0, last_gmax = 0;
   size_t chol_lds = 0;
@@ -124,6 +128,27 @@ int do_allreduce(lifcal_ba_handle* h, double* buf, size_t count) {
   if (h->comm) { if (g_rccl.AllReduce(buf, buf, count, kNcclFloat64, kNcclSum, h->comm, h->stream) != 0) { g_last_error = "ncclAllReduce failed"; return LIFCAL_BA_ERR_COMM; } return 0; }
   g_last_error = "world_size > 1 but neither lifcal_ba_set_allreduce nor lifcal_ba_comm_init_rccl was called";
   return LIFCAL_BA_ERR_COMM;
+}
+
+// sum of the per-rank partial reduced blocks: slab all-gather + local add where it applies, else one sum all-reduce
+int exchange_reduced(lifcal_ba_handle* h) {
+  if (h->opt.world_size <= 1) return 0;
+  const bool have_gather = h->ghook ? (h->hook != nullptr) : (h->hook == nullptr && h->comm != nullptr);
+  if (!h->xch_ok || !have_gather) return do_allreduce(h, h->red_block, h->red_count);
+  const Xch& x = h->xch;
+  hipLaunchKernelGGL(k_xch_pack, dim3((x.SL + 255) / 256), dim3(256), 0, h->stream, h->d, x);
+  HIP_TRY(hipGetLastError());
+  if (h->ghook) {
+    if (h->ghook(h->ghook_ctx, x.send, (void*)x.recv, x.SL, (void*)h->stream) != 0) { g_last_error = "all-gather hook failed"; return LIFCAL_BA_ERR_COMM; }
+  } else if (g_rccl.AllGather(x.send, (void*)x.recv, x.SL, kNcclFloat64, h->comm, h->stream) != 0) {
+    // the partial block is still intact (packing only reads it): take the plain all-reduce from now on
+    h->xch_ok = false;
+    return do_allreduce(h, h->red_block, h->red_count);
+  }
+  const size_t n = (size_t)(x.F6 / 6) * x.BS + (size_t)x.NA * x.F6 + (size_t)3 * x.F6 + x.NA * x.NA + 3 * x.NA + SCAL_N;
+  hipLaunchKernelGGL(k_xch_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->d, x);
+  HIP_TRY(hipGetLastError());
+  return 0;
 }
 
 #define DISPATCH_CFG(h, CALL)                                                       \
@@ -220,7 +245,7 @@ int launch_sweep(lifcal_ba_handle* h, double radius) {
   if (int rc = launch_blocks(h, radius, 0, zeroed)) return rc;
   if (d.use_points && d.n_special) hipLaunchKernelGGL(k_schur, dim3((d.n_special + 3) / 4), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
-  if (int rc = do_allreduce(h, h->red_block, h->red_count)) return rc;
+  if (int rc = exchange_reduced(h)) return rc;
   hipLaunchKernelGGL(k_finalize, dim3((d.n_red + 255) / 256), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
   if (h->prof_active()) { HIP_TRY(hipEventRecord(h->prof_ev(5), h->stream)); h->prof_used++; }   // event 5 of the LAST sweep closes the timed span
@@ -519,6 +544,23 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   A(h->red_block, h->red_count);
   d.Sband = h->red_block; d.Sarrow = d.Sband + n_band; d.rhsacc = d.Sarrow + n_arrow; d.gB = d.rhsacc + d.n_red; d.hdiag = d.gB + d.n_red; d.scal = d.hdiag + d.n_red;
   A(d.sig_red, d.n_red); A(d.lam_red, d.n_red); A(d.delta_red, d.n_red); A(d.Linv, (size_t)d.F * 36 + 36);
+  // multi-GPU: slab exchange of the reduced block (every rank's partial block lives in one frame range)
+  if (opt.world_size > 1 && d.Q == 0 && d.use_poses && getenv("LIFCAL_DENSE_ALLREDUCE") == nullptr) {
+    Xch& x = h->xch;
+    x.world = (uint32_t)opt.world_size; x.rank = (uint32_t)opt.rank; x.BS = (d.bw + 1) * 36; x.NA = d.NA; x.F6 = 6 * d.F;
+    uint32_t maxn = 1;
+    for (uint32_t n : L.rk_nfr) maxn = std::max(maxn, n);
+    x.maxn = maxn;
+    const uint64_t off_arrow = (uint64_t)maxn * x.BS, off_vec = off_arrow + (uint64_t)maxn * x.NA * 6, off_tail = off_vec + (uint64_t)maxn * 18;
+    const uint64_t SL = off_tail + (uint64_t)x.NA * x.NA + 3 * x.NA + SCAL_N;
+    // worth it only if the gathered slabs are smaller than what a ring all-reduce moves (2x the block)
+    if (SL < (1ull << 31) && (uint64_t)x.world * SL <= 2 * (uint64_t)h->red_count) {
+      x.off_arrow = (uint32_t)off_arrow; x.off_vec = (uint32_t)off_vec; x.off_tail = (uint32_t)off_tail; x.SL = (uint32_t)SL;
+      uint32_t* t; U(t, L.rk_flo); x.flo = t; U(t, L.rk_nfr); x.nfr = t;
+      double* b; A(b, (size_t)SL); x.send = b; A(b, (size_t)x.world * SL); x.recv = b;
+      h->xch_ok = true;
+    }
+  }
   A(d.dbg, (size_t)std::max(1u, d.n_blocks) * 16);
   A(d.dP, 3 * (size_t)d.P); A(h->ls_buf, 8);
   A(d.step, ST_N); A(h->partial, 8); A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->pts_gather, 3 * (size_t)d.P);
@@ -565,6 +607,12 @@ int lifcal_ba_download_parameters(lifcal_ba_handle* h) { return h ? download_par
 int lifcal_ba_set_allreduce(lifcal_ba_handle* h, lifcal_ba_allreduce_fn fn, void* ctx) {
   if (!h) return LIFCAL_BA_ERR_INVALID_ARG;
   h->hook = fn; h->hook_ctx = ctx;
+  return 0;
+}
+
+int lifcal_ba_set_allgather(lifcal_ba_handle* h, lifcal_ba_allgather_fn fn, void* ctx) {
+  if (!h) return LIFCAL_BA_ERR_INVALID_ARG;
+  h->ghook = fn; h->ghook_ctx = ctx;
   return 0;
 }
 

@@ -67,6 +67,7 @@ struct Plan {
   // pass   = <= 256 groups / <= 64 points of a block (4 tiles, group g -> wave g%4, lane g/4)
   static constexpr uint32_t NF_MAX = 20, NP_MAX = 64, PASS_GROUPS = 256, ZD_DOUBLES = 8192;
   uint32_t n_blocks = 0, n_passes = 0, max_block_nf = 0;
+  std::vector<uint32_t> rk_flo, rk_nfr;   // per rank: first frame and number of frames its points observe (identical on every rank)
   uint32_t n_pairs = 0;                // (point, frame) pairs with observations; n_groups counts LANES (pairs after splitting)
   std::vector<uint32_t> blk_pass0;     // n_blocks+1
   std::vector<uint32_t> blk_flo, blk_nf;
@@ -168,6 +169,12 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   }
   L.owned_points.clear();
   for (uint32_t r = 0; r < L.P; ++r) { const uint32_t q = L.point_order[r]; if (L.owner[q] == rank) L.owned_points.push_back(q); }
+  {
+    std::vector<uint32_t> lo(world, UINT32_MAX), hi(world, 0);
+    for (uint32_t q = 0; q < L.P; ++q) if (cnt[q] && L.owner[q] >= 0) { lo[L.owner[q]] = std::min(lo[L.owner[q]], first[q]); hi[L.owner[q]] = std::max(hi[L.owner[q]], last[q]); }
+    L.rk_flo.assign(world, 0); L.rk_nfr.assign(world, 0);
+    for (int r = 0; r < world; ++r) if (lo[r] != UINT32_MAX) { L.rk_flo[r] = lo[r]; L.rk_nfr[r] = hi[r] - lo[r] + 1; }
+  }
 
   // --- local observations sorted by (point order, frame) ---
   std::vector<uint32_t> order_rank(L.P, 0);

@@ -1,6 +1,7 @@
-"""Two ranks on ONE GPU: real inter-process exchange through the all-reduce hook (torch.distributed, gloo),
-so sharding, the iteration-0 Jacobi all-reduce, the LM loop and the final point gather run as they do on N GPUs
-(only RCCL itself is replaced).  Rank 0 compares with the single-process oracle."""
+"""Two (or three) ranks on ONE GPU: real inter-process exchange through the collective hooks (torch.distributed,
+gloo), so sharding, the iteration-0 Jacobi all-reduce, the slab all-gather of the reduced block, the LM loop and the
+final point gather run as they do on N GPUs (only RCCL itself is replaced).  Rank 0 compares with the single-process
+oracle."""
 import ctypes as C
 import os
 import sys
@@ -15,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out_dir, spec_kw):
+def _worker(rank, world, port, out_dir, spec_kw, mode):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -37,12 +38,27 @@ def _worker(rank, world, port, out_dir, spec_kw):
         hip.hipMemcpy(ptr, buf.ctypes.data, count * 8, 1)
         return 0
     ba.set_allreduce(hook)
+    calls = {"gather": 0, "gather_doubles": 0}
+
+    def ghook(send, recv, count, stream):
+        hip.hipStreamSynchronize(stream)
+        buf = np.empty(count)
+        hip.hipMemcpy(buf.ctypes.data, send, count * 8, 2)
+        parts = [torch.empty(count, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(parts, torch.from_numpy(buf))
+        allb = torch.cat(parts).numpy()
+        hip.hipMemcpy(recv, allb.ctypes.data, world * count * 8, 1)
+        calls["gather"] += 1; calls["gather_doubles"] = count
+        return 0
+    if mode == "allgather":
+        ba.set_allgather(ghook)
     sw = ba.sweep(1e4, want_matrices=(rank == 0))
     summ = ba.performBundleAdjustment()
     st = ba.calcReprojectionError()
     info = ba.info()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cam=pa.cam, views=pa.views, pts=pa.pts, cost0=sw.cost,
              S=sw.S if rank == 0 else np.zeros(1), rhs=sw.rhs if rank == 0 else np.zeros(1),
+             gather_calls=calls["gather"], gather_doubles=calls["gather_doubles"], n_red=info.n_reduced,
              it=summ.iterations, term=summ.termination, final=summ.final_cost, n_local=info.n_obs_local,
              stats=np.array([st.std_x, st.std_y, st.num_points, st.num_inliers]))
     ba.close()
@@ -50,23 +66,32 @@ def _worker(rank, world, port, out_dir, spec_kw):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("spec_kw", [
-    dict(n_frames=24, n_points=160, window=6, config=0xF06, seed=1401, outlier_fraction=0.02),
-    dict(n_frames=8, n_points=60, window=None, config=0x506, seed=1402, n_constraints=3),
-], ids=["windowed_robust", "constraints"])
-def test_two_ranks_match_the_single_process_oracle(built, tmp_path, spec_kw):
+@pytest.mark.parametrize("spec_kw,mode,world", [
+    (dict(n_frames=24, n_points=160, window=6, config=0xF06, seed=1401, outlier_fraction=0.02), "allreduce", 2),
+    (dict(n_frames=8, n_points=60, window=None, config=0x506, seed=1402, n_constraints=3), "allreduce", 2),
+    (dict(n_frames=24, n_points=160, window=6, config=0xF06, seed=1401, outlier_fraction=0.02), "allgather", 2),
+    (dict(n_frames=60, n_points=400, window=8, config=0xF06, seed=1403, outlier_fraction=0.02), "allgather", 3),
+    (dict(n_frames=8, n_points=60, window=None, config=0x506, seed=1402, n_constraints=3), "allgather", 2),
+], ids=["windowed_robust", "constraints", "windowed_robust_slabs", "three_ranks_slabs", "constraints_fall_back_to_allreduce"])
+def test_ranks_match_the_single_process_oracle(built, tmp_path, spec_kw, mode, world):
     import oracle
     from lifcal_amd import _capi as capi, scene
     from tests.helpers import scaled_max_err, vec_err
-    world = 2
     port = 29700 + (os.getpid() % 1500)
-    mp.spawn(_worker, args=(world, port, str(tmp_path), spec_kw), nprocs=world, join=True)
-    r0 = np.load(os.path.join(str(tmp_path), "rank0.npz")); r1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+    mp.spawn(_worker, args=(world, port, str(tmp_path), spec_kw, mode), nprocs=world, join=True)
+    r0 = np.load(os.path.join(str(tmp_path), "rank0.npz")); r1 = np.load(os.path.join(str(tmp_path), f"rank{world - 1}.npz"))
+    if mode == "allgather" and not spec_kw.get("n_constraints"):
+        # the reduced block went through the slab exchange, and a slab is well below the whole block
+        n_red = int(r0["n_red"])
+        assert int(r0["gather_calls"]) > 0 and int(r0["gather_doubles"]) < 0.8 * (n_red * (n_red + 1) // 2)
+    else:
+        assert int(r0["gather_calls"]) == 0
     sc = scene.make_scene(scene.SceneSpec(**spec_kw))
     ref = oracle.sweep(capi.ProblemArrays.from_scene(sc), radius=1e4, threads=4)
     assert abs(float(r0["cost0"]) - ref.cost) <= 1e-12 * ref.cost and abs(float(r1["cost0"]) - ref.cost) <= 1e-12 * ref.cost
     assert scaled_max_err(r0["S"], ref.S) < 1e-9 and vec_err(r0["rhs"], ref.rhs) < 1e-9
-    assert int(r0["n_local"]) + int(r1["n_local"]) == sc.n_obs and min(int(r0["n_local"]), int(r1["n_local"])) > 0.3 * sc.n_obs
+    n_local = [int(np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))["n_local"]) for r in range(world)]
+    assert sum(n_local) == sc.n_obs and min(n_local) > 0.6 * sc.n_obs / world
     pb = capi.ProblemArrays.from_scene(sc)
     so = oracle.solve(pb, threads=4)
     for r in (r0, r1):   # every rank ends with the full, identical result
