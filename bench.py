@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solve", action="store_true", help="skip the full LM solve after the timed sweeps (profiling runs: only sweep kernels in the trace)")
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
                     help="rccl: library-owned RCCL communicator (default, one GPU per rank); gloo: rehearsal of the multi-process path on ONE GPU (all ranks on cuda:0, all-reduce through host memory)")
     args = ap.parse_args()
@@ -199,7 +200,7 @@ def main():
     # second half of the BASELINE metric: final RMS reprojection error after the full LM solve (outside the timed region)
     # (N = 1 only, like the CPU baseline: the weak-scaled N > 1 problem is a different scene; never let it cost the bench line)
     solve = None
-    if world == 1:
+    if world == 1 and not args.no_solve:
         try:
             before = ba.calcReprojectionError(1.0)
             torch.cuda.synchronize()

@@ -57,7 +57,9 @@ struct Dev {
   const uint8_t* frame_live;     // F
   double *ptacc;                 // P*36: U(6) g(3) Wc(27)
   double *Uinv, *lamP, *sigP;    // 9P, 3P, 3P
-  double *Wv;                    // 18 per slot
+  double *Wv;                    // 18 per slot: W_pose of the groups of SPECIAL points (v1 kernels)
+  double *Av;                    // 6 per slot: camera-frame block A = sum Jq^T Jq of the lanes of REGULAR points; W_pose = R^T A [Gr | I] is rebuilt in k_backsub
+  const uint8_t* pt_special;     // P: 1 = the point takes the v1 kernels
   const uint32_t *gid_fr, *slot_gid;              // frame of each group id; v1 path: group id of each slot
   // v2 (LDS-window) path
   uint32_t n_blocks, v2_nfmax, n_special;
@@ -831,11 +833,39 @@ __global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by th
       double v[3] = {acc[6], acc[7], acc[8]};
       const uint32_t ns = d.pt_nslots[p];
       const uint32_t ncon = d.pt_cons0 ? d.pt_cons0[p + 1] - d.pt_cons0[p] : 0;
-      for (uint32_t bi = 0; bi < 1 + ns + ncon; ++bi) {
-        const WBlock B = point_block(d, p, bi, ns);
-        for (uint32_t j = 0; j < B.width; ++j) {
-          const double dl = d.delta_red[B.base + j];
-          v[0] += B.W[j] * dl; v[1] += B.W[B.ldw + j] * dl; v[2] += B.W[2 * B.ldw + j] * dl;
+      if (d.pt_special[p]) {
+        for (uint32_t bi = 0; bi < 1 + ns + ncon; ++bi) {
+          const WBlock B = point_block(d, p, bi, ns);
+          for (uint32_t j = 0; j < B.width; ++j) {
+            const double dl = d.delta_red[B.base + j];
+            v[0] += B.W[j] * dl; v[1] += B.W[B.ldw + j] * dl; v[2] += B.W[2 * B.ldw + j] * dl;
+          }
+        }
+      } else {
+        // regular point (LDS-window kernel): the sweep stored only A per lane; W_pose delta_f = R^T A (Gr delta_a + delta_t)
+        // with Gr = d(R P)/d(angles) rebuilt from the frame table and the point (k_sweep2's emission, same formulas)
+        { const WBlock B = point_block(d, p, 0, ns);
+          for (uint32_t j = 0; j < B.width; ++j) { const double dl = d.delta_red[B.base + j]; v[0] += B.W[j] * dl; v[1] += B.W[B.ldw + j] * dl; v[2] += B.W[2 * B.ldw + j] * dl; } }
+        const double P0 = d.pts[3 * (size_t)p], P1 = d.pts[3 * (size_t)p + 1], P2 = d.pts[3 * (size_t)p + 2];
+        const uint32_t s0 = d.pt_slot0[p];
+        for (uint32_t k = 0; k < ns; ++k) {
+          const uint32_t sidx = s0 + k, f = d.gid_fr[sidx];
+          const double* ft = d.ft + (size_t)f * FRAME_STRIDE;
+          const double* A = d.Av + (size_t)sidx * 6;
+          const double* dl = d.delta_red + 6 * f;
+          double R[9];
+#pragma unroll
+          for (int i = 0; i < 9; ++i) R[i] = ft[i];
+          const double c0 = ft[12], sn0 = ft[13];
+          const double Y0 = R[0] * P0 + R[1] * P1 + R[2] * P2, Y1 = R[3] * P0 + R[4] * P1 + R[5] * P2, Y2 = R[6] * P0 + R[7] * P1 + R[8] * P2;
+          const double n0 = R[2], n1 = R[5], n2 = R[8];
+          // t = Gr delta_a + delta_t, Gr columns: e_x x Y, (0,c0,s0) x Y, R[:,2] x Y
+          const double a0 = dl[0], a1 = dl[1], a2 = dl[2];
+          const double t0 = (c0 * Y2 - sn0 * Y1) * a1 + (n1 * Y2 - n2 * Y1) * a2 + dl[3];
+          const double t1 = -Y2 * a0 + (sn0 * Y0) * a1 + (n2 * Y0 - n0 * Y2) * a2 + dl[4];
+          const double t2 = Y1 * a0 + (-c0 * Y0) * a1 + (n0 * Y1 - n1 * Y0) * a2 + dl[5];
+          const double u0 = A[0] * t0 + A[1] * t1 + A[2] * t2, u1 = A[1] * t0 + A[3] * t1 + A[4] * t2, u2 = A[2] * t0 + A[4] * t1 + A[5] * t2;
+          v[0] += R[0] * u0 + R[3] * u1 + R[6] * u2; v[1] += R[1] * u0 + R[4] * u1 + R[7] * u2; v[2] += R[2] * u0 + R[5] * u1 + R[8] * u2;
         }
       }
       const double* iv = d.Uinv + 9 * (size_t)p;

@@ -533,6 +533,8 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   A(d.ptacc, (size_t)d.P * 36); A(d.Uinv, (size_t)d.P * 9);
   if (hipMemset(d.ptacc, 0, (size_t)std::max(1u, d.P) * 36 * sizeof(double)) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); A(d.lamP, (size_t)d.P * 3); A(d.sigP, (size_t)d.P * 3);
   A(d.Wv, (size_t)L.n_groups * 18);
+  A(d.Av, (size_t)L.n_groups * 6);
+  { uint8_t* t; U(t, L.pt_special); d.pt_special = t; }
   if (L.use_constraints) {
     uint32_t* t; U(t, L.c_i); d.c_i = t; U(t, L.c_j); d.c_j = t; U(t, L.my_constraints); d.my_cons = t;
     U(t, L.pt_cons0); d.pt_cons0 = t; U(t, L.pt_cons_list); d.pt_cons_list = t;

@@ -67,6 +67,7 @@ struct Plan {
   // pass   = <= 256 groups / <= 64 points of a block (4 tiles, group g -> wave g%4, lane g/4)
   static constexpr uint32_t NF_MAX = 20, NP_MAX = 64, PASS_GROUPS = 256, ZD_DOUBLES = 8192;
   uint32_t n_blocks = 0, n_passes = 0, max_block_nf = 0;
+  std::vector<uint8_t> pt_special;     // P: the point takes the v1 (global-atomic) kernels
   std::vector<uint32_t> rk_flo, rk_nfr;   // per rank: first frame and number of frames its points observe (identical on every rank)
   uint32_t n_pairs = 0;                // (point, frame) pairs with observations; n_groups counts LANES (pairs after splitting)
   std::vector<uint32_t> blk_pass0;     // n_blocks+1
@@ -439,8 +440,9 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     // a point that is only constrained (never observed) still needs an owner
     for (uint32_t c = 0; c < L.M; ++c) if (L.owner[L.c_i[c]] < 0) { L.owner[L.c_i[c]] = 0; if (rank == 0) L.owned_points.push_back(L.c_i[c]); }
   }
+  L.pt_special = special;
   L.special_owned.clear();
-  for (uint32_t q : L.owned_points) if (special[q] || L.pt_nslots[q] == 0) L.special_owned.push_back(q);
+  for (uint32_t q : L.owned_points) if (special[q] || L.pt_nslots[q] == 0) { L.special_owned.push_back(q); L.pt_special[q] = 1; }
   return 0;
 }
 

@@ -7,7 +7,7 @@
 //   slab U(6) g(3) per point of the current pass, Zd = dense (3 np) x (window columns) matrix of the pass
 // A pass = <= 256 groups (group g -> wave g%4, lane g/4).  Per pass:
 //   (1) lanes walk their observations (residual, analytic Jacobian, Cauchy weight) and add their rotated blocks with
-//       LDS f64 atomics; W_pose goes straight to HBM (back-substitution) and into its cell of Zd,
+//       LDS f64 atomics; W_pose goes into its cell of Zd, the lane's 3x3 block A to HBM (back-substitution rebuilds W from it),
 //   (2) one thread per point damps and factors U = L L^T (ceres LevenbergMarquardtStrategy + InvertPSDMatrix<3>),
 //   (3) Zd <- L^-1 W row-wise; rhs column = L^-1 g,
 //   (4) window -= Zd^T Zd as a register-blocked fp64 product (4x4 micro-tiles per lane; on gfx950 v_fmac_f64 beats
@@ -355,7 +355,10 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
           }
         }
         if (mode == 0) {
-          double* gw = d.Wv + (size_t)(gid0 + g) * 18;   // W_pose of this group: straight to HBM for the back-substitution
+          // only A goes to HBM for the back-substitution (48 B per lane): k_backsub rebuilds W_pose = R^T A [Gr | I] from it
+          { double* ga = d.Av + (size_t)(gid0 + g) * 6;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) ga[k] = A[k]; }
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             atomicAdd(acc + 6 + i, R[i] * bv[0] + R[3 + i] * bv[1] + R[6 + i] * bv[2]);
@@ -363,9 +366,9 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #pragma unroll
             for (int j = 0; j < NC; ++j) atomicAdd(zrow + 6 * nf + j, R[i] * C[0][j] + R[3 + i] * C[1][j] + R[6 + i] * C[2][j]);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const double wij = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j]; atomicAdd(zrow + 6 * lf + j, wij); gw[i * 6 + j] = wij; }
+            for (int j = 0; j < 3; ++j) { const double wij = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j]; atomicAdd(zrow + 6 * lf + j, wij); }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const double wij = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j]; atomicAdd(zrow + 6 * lf + 3 + j, wij); gw[i * 6 + 3 + j] = wij; }
+            for (int j = 0; j < 3; ++j) { const double wij = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j]; atomicAdd(zrow + 6 * lf + 3 + j, wij); }
           }
         }
       }
