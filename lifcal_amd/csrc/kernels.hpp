@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void k_sweep(Dev d) {
 
 // one column of the reduced system: ceres LevenbergMarquardtStrategy diagonal (clamp(sigma^2 h) / (radius sigma^2) in the
 // unscaled space), rhs = -g_B + W^T U^-1 g into the rhs arrow row, identity for columns that are not solved for
-LIFCAL_DEV void finalize_column(const Dev& d, uint32_t t, double radius) {
+LIFCAL_DEV double finalize_column(const Dev& d, uint32_t t, double radius) {
   const uint32_t F6 = 6 * d.F;
   bool live;
   if (t < F6) live = d.use_poses && d.frame_live[t / 6];
@@ -366,8 +366,7 @@ LIFCAL_DEV void finalize_column(const Dev& d, uint32_t t, double radius) {
     *diag = 1.0;
     rhs[t] = 0.0;
   }
-  // max |g| over the reduced block (bit pattern of a non-negative double orders like an integer)
-  atomicMax((unsigned long long*)(d.step + ST_GMAX_RED), (unsigned long long)__double_as_longlong(fabs(d.gB[t])));
+  return fabs(d.gB[t]);
 }
 
 }  // namespace lifcal
@@ -625,7 +624,12 @@ __global__ void k_xch_unpack(Dev d, Xch x) {
 // ---------------------------------------------------------------------------------------------
 __global__ void k_finalize(Dev d, double radius) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < d.n_red) finalize_column(d, t, radius);
+  double g = 0.0;
+  if (t < d.n_red) g = finalize_column(d, t, radius);
+  // max |g| over the reduced block: one atomic per wave (bit pattern of a non-negative double orders like an integer)
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) g = fmax(g, __shfl_xor(g, m, 64));
+  if ((threadIdx.x & 63u) == 0) atomicMax((unsigned long long*)(d.step + ST_GMAX_RED), (unsigned long long)__double_as_longlong(g));
 }
 
 // ---------------------------------------------------------------------------------------------

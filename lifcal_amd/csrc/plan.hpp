@@ -271,41 +271,56 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   // --- lanes: a (point, frame) group of a regular point with more than T observations is cut into near-equal parts, one
   // lane each.  A wave walks max(lane size) observation steps, so this trades a few more lanes (and their block emission)
   // for fewer idle steps; every consumer (LDS accumulation, W staging, back-substitution) is linear in the per-lane
-  // blocks, so two lanes with the same (point, frame) simply add up.  T is chosen per block from a cost model of
-  // k_sweep2 (cycles measured with the in-kernel stamps at the 1 M-observation point): more lanes can mean one more pass.
+  // blocks, so two lanes with the same (point, frame) simply add up.  T is chosen per PASS by a small dynamic program
+  // over a cost model of k_sweep2 (cycles measured with the in-kernel stamps at the 1 M-observation point).
   L.n_pairs = L.n_groups;
+  std::vector<uint8_t> pass_break(L.P, 0);   // a pass of the plan below starts at this point
   {
     std::vector<uint32_t> split_of(L.P, 0);   // 0 = leave the point's groups whole
     auto parts_of = [](uint32_t n, uint32_t T) { return T ? (n + T - 1) / T : 1u; };
+    constexpr double C_STEP = 4700.0, C_PASS = 21500.0, C_LANE = 65.0;   // cycles per observation step of a pass, per pass, per lane
     for (size_t b = 0; b + 1 < blk_begin.size(); ++b) {
       const uint32_t np_cap = block_np_cap(b);
+      const size_t i0 = blk_begin[b], n = blk_begin[b + 1] - i0;
       uint32_t nmax = 0;
-      for (size_t k = blk_begin[b]; k < blk_begin[b + 1]; ++k)
-        for (uint32_t g = L.pt_slot0[reg[k]]; g < L.pt_slot0[reg[k]] + L.pt_nslots[reg[k]]; ++g) nmax = std::max(nmax, groups[g].n);
-      auto model = [&](uint32_t T, bool& ok) {
-        constexpr double C_STEP = 4500.0, C_PASS = 21500.0, C_LANE = 45.0;
-        uint32_t passes = 0, ng = 0, npp = 0, steps = 0; uint64_t lanes = 0;
-        ok = true;
-        for (size_t k = blk_begin[b]; k < blk_begin[b + 1]; ++k) {
-          uint32_t l = 0;
-          for (uint32_t g = L.pt_slot0[reg[k]]; g < L.pt_slot0[reg[k]] + L.pt_nslots[reg[k]]; ++g) {
-            const uint32_t parts = parts_of(groups[g].n, T);
-            l += parts; steps = std::max(steps, (groups[g].n + parts - 1) / parts);
+      for (size_t k = 0; k < n; ++k)
+        for (uint32_t g = L.pt_slot0[reg[i0 + k]]; g < L.pt_slot0[reg[i0 + k]] + L.pt_nslots[reg[i0 + k]]; ++g) nmax = std::max(nmax, groups[g].n);
+      // candidate split sizes: 0 (whole groups) and, in automatic mode, 2 .. min(largest group, 16); a fixed request otherwise
+      std::vector<uint32_t> Ts(1, 0u);
+      if (split_obs == UINT32_MAX) { for (uint32_t T = 2; T <= std::min(nmax, 16u); ++T) Ts.push_back(T); }
+      else if (split_obs > 0) Ts.assign(1, split_obs);
+      const size_t nT = Ts.size();
+      std::vector<uint32_t> lanes(n * nT), steps(n * nT);
+      for (size_t k = 0; k < n; ++k)
+        for (size_t t = 0; t < nT; ++t) {
+          uint32_t l = 0, st = 0;
+          for (uint32_t g = L.pt_slot0[reg[i0 + k]]; g < L.pt_slot0[reg[i0 + k]] + L.pt_nslots[reg[i0 + k]]; ++g) {
+            const uint32_t parts = parts_of(groups[g].n, Ts[t]);
+            l += parts; st = std::max(st, (groups[g].n + parts - 1) / parts);
           }
-          if (l > Plan::PASS_GROUPS / 4) ok = false;     // keep several points per pass
-          if (passes == 0 || npp >= np_cap || ng + l > Plan::PASS_GROUPS) { ++passes; ng = 0; npp = 0; }
-          ng += l; ++npp; lanes += l;
+          lanes[k * nT + t] = l; steps[k * nT + t] = st;
         }
-        return passes * (C_STEP * steps + C_PASS) + C_LANE * (double)lanes;
-      };
-      uint32_t best_T = 0; bool ok;
-      double best = model(0, ok);
-      if (split_obs == UINT32_MAX) {            // automatic
-        for (uint32_t T = std::min(nmax, 16u); T >= 2; --T) { const double c = model(T, ok); if (ok && c < best) { best = c; best_T = T; } }
-      } else if (split_obs > 0) {
-        model(split_obs, ok); if (ok) best_T = split_obs;
+      // dynamic program over the block's points: a pass = maximal run of points that fits 256 lanes / np_cap points at ONE
+      // split size; cost[i] = cheapest way to cover points i.. (more lanes can mean one more pass, fewer steps per pass)
+      std::vector<double> cost(n + 1, 0.0);
+      std::vector<uint32_t> pick(n, 0), nxt(n, 0);
+      for (size_t i = n; i-- > 0;) {
+        double best = 1e300;
+        for (size_t t = 0; t < nT; ++t) {
+          uint32_t ng = 0, st = 0; size_t e = i;
+          while (e < n && e - i < np_cap && ng + lanes[e * nT + t] <= Plan::PASS_GROUPS) { ng += lanes[e * nT + t]; st = std::max(st, steps[e * nT + t]); ++e; }
+          if (e == i) continue;                                                  // a single point too wide for this split size
+          if (Ts[t] != 0 && lanes[i * nT + t] > Plan::PASS_GROUPS / 4 && nT > 1) continue;   // keep several points per pass
+          const double c = C_STEP * st + C_PASS + C_LANE * ng + cost[e];
+          if (c < best) { best = c; pick[i] = (uint32_t)t; nxt[i] = (uint32_t)e; }
+        }
+        if (best == 1e300) { pick[i] = 0; nxt[i] = (uint32_t)i + 1; best = C_PASS + cost[i + 1]; }   // whole groups always fit (regular points have <= 256 groups)
+        cost[i] = best;
       }
-      for (size_t k = blk_begin[b]; k < blk_begin[b + 1]; ++k) split_of[reg[k]] = best_T;
+      for (size_t i = 0; i < n; i = nxt[i]) {
+        for (size_t k = i; k < nxt[i]; ++k) split_of[reg[i0 + k]] = Ts[pick[i]];
+        if (i > 0) pass_break[reg[i0 + i]] = 1;
+      }
     }
     std::vector<Group> cut;
     cut.reserve(groups.size() * 2);
@@ -367,7 +382,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     while (a < j) {
       uint32_t ng = 0, np = 0; size_t e = a;
       // a pass covers one contiguous run of gids (a special point's groups in between end the pass)
-      while (e < j && np < np_cap && ng + L.pt_nslots[reg[e]] <= Plan::PASS_GROUPS &&
+      while (e < j && np < np_cap && ng + L.pt_nslots[reg[e]] <= Plan::PASS_GROUPS && !(e > a && pass_break[reg[e]]) &&
              (e == a || L.pt_slot0[reg[e]] == L.pt_slot0[reg[e - 1]] + L.pt_nslots[reg[e - 1]])) { ng += L.pt_nslots[reg[e]]; ++np; ++e; }
       L.pass_pt0.push_back((uint32_t)L.v2_points.size()); L.pass_np.push_back(np);
       L.pass_gid0.push_back(L.pt_slot0[reg[a]]); L.pass_ng.push_back(ng);
