@@ -371,6 +371,7 @@ LIFCAL_DEV double finalize_column(const Dev& d, uint32_t t, double radius) {
 
 }  // namespace lifcal
 #include "sweep2.hpp"   // k_sweep2: the LDS-window fused sweep (regular points)
+#include "sweep3.hpp"   // k_sweep3: the same with a wave-specialised observation loop (512 threads)
 namespace lifcal {
 
 // ---------------------------------------------------------------------------------------------

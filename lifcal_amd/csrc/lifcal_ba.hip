@@ -80,6 +80,7 @@ struct lifcal_ba_handle {
   uint64_t bytes = 0;
   double* red_block = nullptr; size_t red_count = 0;
   size_t v2_lds_bytes = 0;
+  bool use_sweep3 = true;        // wave-specialised LDS-window kernel (LIFCAL_SWEEP_KERNEL=2 selects k_sweep2)
   TileSet ts1{}, ts2{};   // v1 tiles, v2 tiles (flat view)
   double* partial = nullptr;     // 4 doubles + 1 cand cost (all-reduced)
   double* hdiag_tmp = nullptr;
@@ -203,7 +204,9 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
   if (mode == 0 && h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(1), h->stream));
   if (d.n_blocks) {   // regular points: LDS-window kernel, one workgroup per block
 #define CALL_SWEEP2(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep2<NR, TAN, ADJ>), dim3(d.n_blocks), dim3(256), h->v2_lds_bytes, h->stream, d, radius, mode)
-    DISPATCH_CFG(h, CALL_SWEEP2);
+#define CALL_SWEEP3(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep3<NR, TAN, ADJ>), dim3(d.n_blocks), dim3(512), h->v2_lds_bytes, h->stream, d, radius, mode)
+    if (h->use_sweep3) DISPATCH_CFG(h, CALL_SWEEP3); else DISPATCH_CFG(h, CALL_SWEEP2);
+#undef CALL_SWEEP3
 #undef CALL_SWEEP2
   }
   if (d.n_tiles) {    // special points (constraints, promoted, oversized, camera-only / pose-only arities): global atomics
@@ -520,8 +523,10 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
     h->ts2 = TileSet{4 * L.n_passes, d.v2_tile_row0, a, b, c, d.v2_lens, d.v2_u, d.v2_v}; }
   d.n_blocks = L.n_blocks; d.v2_nfmax = std::max(1u, L.max_block_nf); d.n_special = (uint32_t)L.special_owned.size();
   h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax).total * sizeof(double);
+  h->use_sweep3 = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
   if (d.n_blocks) {
-#define SET_LDS(NR, TAN, ADJ) do { if (hipFuncSetAttribute((const void*)k_sweep2<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); } while (0)
+#define SET_LDS(NR, TAN, ADJ) do { if (hipFuncSetAttribute((const void*)k_sweep2<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
+    if (hipFuncSetAttribute((const void*)k_sweep3<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); } while (0)
     DISPATCH_CFG(h, SET_LDS);
 #undef SET_LDS
   }
@@ -563,7 +568,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
       h->xch_ok = true;
     }
   }
-  A(d.dbg, (size_t)std::max(1u, d.n_blocks) * 16);
+  A(d.dbg, (size_t)std::max(1u, d.n_blocks) * 32);
   A(d.dP, 3 * (size_t)d.P); A(h->ls_buf, 8);
   A(d.step, ST_N); A(h->partial, 8); A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->pts_gather, 3 * (size_t)d.P);
   // Cholesky panel: LDS when it fits (<= 64 KiB by default launch limits), else a global scratch
@@ -637,12 +642,12 @@ int lifcal_ba_comm_init_rccl(lifcal_ba_handle* h, const void* unique_id128) {
 }
 
 #ifdef LIFCAL_STAMPS
-// diagnostic build only: copies the per-block phase cycle counters of the last k_sweep2 launch (16 per block)
+// diagnostic build only: copies the per-block phase cycle counters of the last k_sweep2 launch (32 per block: 16 of thread 0, 16 of thread 256)
 extern "C" int lifcal_ba_debug_stamps(lifcal_ba_handle* h, unsigned long long* out, uint32_t max_blocks) {
   if (!h || !out) return LIFCAL_BA_ERR_INVALID_ARG;
   const uint32_t n = std::min(max_blocks, h->d.n_blocks);
   HIP_TRY(hipStreamSynchronize(h->stream));
-  HIP_TRY(hipMemcpy(out, h->d.dbg, (size_t)n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  HIP_TRY(hipMemcpy(out, h->d.dbg, (size_t)n * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return (int)n;
 }
 #endif

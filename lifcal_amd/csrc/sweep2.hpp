@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
         // frame-level values go to this lane's replica, value-major: every lane of the wave instruction hits its own address
         // slot = frame * R + replica: consecutive doubles across the lanes of one instruction (bank-ideal, no address clash)
         const uint32_t frs = NFm * lay.nrep;
-        double* fr_acc = Fr + (size_t)lf * lay.nrep + rep;
+        double* fr_acc = Fr + (size_t)rep * NFm + lf;   // replica-major: the lanes of a wave instruction land on one compact run of doubles
         {
           int vi = 0;
 #pragma unroll
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
   for (uint32_t i = tid; i < FRV * nf; i += 256) {
     const uint32_t v = i / nf, lf = i % nf;
     double sacc = 0.0;
-    for (uint32_t r = 0; r < lay.nrep; ++r) sacc += Fr[(size_t)v * NFm * lay.nrep + lf * lay.nrep + r];
+    for (uint32_t r = 0; r < lay.nrep; ++r) sacc += Fr[(size_t)v * NFm * lay.nrep + r * NFm + lf];
     if (v < 21) {
       uint32_t a = 0; while ((a + 1) * (a + 2) / 2 <= v) ++a;
       const uint32_t bb = v - a * (a + 1) / 2;
@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 #ifdef LIFCAL_STAMPS
   __syncthreads();
   STAMP(5);
-  if (tid == 0 && d.dbg) for (int i = 0; i < 16; ++i) d.dbg[(size_t)b * 16 + i] = st_acc[i];
+  if (tid == 0 && d.dbg) for (int i = 0; i < 16; ++i) d.dbg[(size_t)b * 32 + i] = st_acc[i];
 #endif
 }
 

@@ -72,6 +72,21 @@ def test_group_splitting_does_not_change_the_result(built, tmp_path, split):
     assert vec_err(a["pg"], b["pg"]) < 1e-11 and vec_err(a["ui"], b["ui"]) < 1e-10
 
 
+@pytest.mark.parametrize("spec_args", [
+    "24, 160, 6, 0xF06, 1207, outlier_fraction=0.02",
+    "12, 90, None, 0x501, 1208",
+    "30, 250, 9, 0xD04, 1209",
+])
+def test_wave_specialised_and_single_role_window_kernels_agree(built, tmp_path, spec_args):
+    """k_sweep3 (512 threads, evaluator / accumulator waves, default) against k_sweep2 (LIFCAL_SWEEP_KERNEL=2)"""
+    a = run_child(tmp_path, spec_args, {}, "k3")
+    b = run_child(tmp_path, spec_args, {"LIFCAL_SWEEP_KERNEL": "2"}, "k2")
+    assert int(a["chunks"]) > 0 and int(b["chunks"]) > 0
+    assert abs(float(a["cost"]) - float(b["cost"])) <= 1e-13 * float(b["cost"])
+    assert scaled_max_err(a["S"], b["S"]) < 1e-11 and vec_err(a["rhs"], b["rhs"]) < 1e-11
+    assert vec_err(a["pg"], b["pg"]) < 1e-12 and vec_err(a["ui"], b["ui"]) < 1e-11
+
+
 def test_mixed_regular_and_oversized_points(built):
     """a few points are also seen 25 frames later (span > 20 frame window): they take the fallback path, the rest v2"""
     sc = scene.make_scene(S(40, 300, 8, 0xF06, 1205, outlier_fraction=0.02))
