@@ -59,25 +59,42 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
   for (uint32_t j = 0; j < F; ++j) {
     const uint32_t sj = slot(j);
     if (lane == 0) {   // 6x6 Cholesky and the inverse of its factor
-      double L[6][6];
+      // One lane, a pure dependency chain: reciprocal square roots only (v_rsq_f64 + Newton steps) — the sqrt + divide
+      // pairs of the textbook form were most of the time of a chain step.  ir[c] = 1 / L[c][c].
+      double L[6][6], ir[6];
       for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) L[a][b] = Wd[(size_t)(sj + a) * nw + sj + b];
       bool ok = true;
+#pragma unroll
       for (int cI = 0; cI < 6; ++cI) {
         double dg = L[cI][cI];
+#pragma unroll
         for (int k = 0; k < cI; ++k) dg -= L[cI][k] * L[cI][k];
         if (!(dg > 0.0)) { ok = false; dg = 1.0; }
-        dg = sqrt(dg); L[cI][cI] = dg;
-        const double idg = 1.0 / dg;
-        for (int r = cI + 1; r < 6; ++r) { double s = L[r][cI]; for (int k = 0; k < cI; ++k) s -= L[r][k] * L[cI][k]; L[r][cI] = s * idg; }
+        const double idg = rsqrt(dg);
+        ir[cI] = idg; L[cI][cI] = dg * idg;
+#pragma unroll
+        for (int r = cI + 1; r < 6; ++r) { double s = L[r][cI];
+#pragma unroll
+          for (int k = 0; k < cI; ++k) s -= L[r][k] * L[cI][k];
+          L[r][cI] = s * idg; }
       }
       if (!ok) *failp = 1.0;
       double I[6][6];
+#pragma unroll
       for (int cI = 0; cI < 6; ++cI) {
+#pragma unroll
         for (int r = 0; r < 6; ++r) I[r][cI] = 0.0;
-        I[cI][cI] = 1.0 / L[cI][cI];
-        for (int r = cI + 1; r < 6; ++r) { double s = 0.0; for (int k = cI; k < r; ++k) s -= L[r][k] * I[k][cI]; I[r][cI] = s / L[r][r]; }
+        I[cI][cI] = ir[cI];
+#pragma unroll
+        for (int r = cI + 1; r < 6; ++r) { double s = 0.0;
+#pragma unroll
+          for (int k = cI; k < r; ++k) s -= L[r][k] * I[k][cI];
+          I[r][cI] = s * ir[r]; }
       }
-      for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) { Li[a * 6 + b] = (b <= a) ? I[a][b] : 0.0; }
+#pragma unroll
+      for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int b = 0; b < 6; ++b) { Li[a * 6 + b] = (b <= a) ? I[a][b] : 0.0; }
       for (int k = 0; k < 36; ++k) d.Linv[(size_t)j * 36 + k] = Li[k];
     }
     __syncthreads();
@@ -112,6 +129,8 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
       if (lane < NAx * 6) pfv[2] = d.Sarrow[(size_t)(lane / 6) * ld + 6 * f + lane % 6];
     }
     // rank-6 update of the window: thread = (row r = tid mod 64 [+64..], column phase tid / 64), columns c <= r step 4
+    // (a 4x4-blocked mapping with one block per thread was measured: slower, the step is bound by its barriers and the
+    // single-lane diagonal factor, not by this update)
     for (uint32_t r = lane & 63u; r < nrows; r += 64) {
       const uint32_t wr = wmap[r];
       const double* pr = Pn + (size_t)r * 6;
@@ -182,30 +201,69 @@ __global__ __launch_bounds__(64) void k_band_backsolve_w(Dev d, const double* Lp
     for (uint32_t b = lane; b < (uint32_t)a; b += 64) xs[6 * F + b] -= Aa[(size_t)a * ld + b] * xa;
     __syncthreads();
   }
+  // One wave walks the chain backwards.  The packed panel of the NEXT column (two rows per lane + the y_j entry of lanes 0-5)
+  // is requested before the current column is reduced, the reduction runs on DPP (no LDS crossbar shuffles), and the
+  // rhs row is read where it is needed instead of being summed over the wave.
+  const uint32_t prow = 6 * bw + NAx;   // panel rows reserved per column
+  double nx[2][6], ny = 0.0;
+  auto fetch = [&](int jj) {
+    const uint32_t nb = min(bw, F - 1 - (uint32_t)jj), nr = 6 * nb + NAx;
+    const double* Lp = Lpanel + (size_t)jj * prow * 6;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t r = lane + 64 * q;
+      const double* row = Lp + (size_t)(r < nr - 1 ? r : 0) * 6;   // clamped: always a valid address, masked at use
+#pragma unroll
+      for (int k = 0; k < 6; ++k) nx[q][k] = row[k];
+    }
+    ny = Lp[(size_t)(nr - 1) * 6 + (lane < 6 ? lane : 0)];          // y_j: the rhs row of the panel (forward substitution done by the factorisation)
+  };
+  if (F > 0) fetch((int)F - 1);
   for (int j = (int)F - 1; j >= 0; --j) {
     const uint32_t nbel = min(bw, F - 1 - (uint32_t)j);
     const uint32_t nrows = 6 * nbel + NAx;
-    const double* Lp = Lpanel + (size_t)j * (6 * bw + NAx) * 6;
-    double acc[6] = {0, 0, 0, 0, 0, 0};
-    double yj[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t r = lane; r < nrows; r += 64) {
-      const double* row = Lp + (size_t)r * 6;
-      if (r == nrows - 1) {   // the rhs row of this panel holds y_j (forward substitution done by the factorisation)
+    const double* Lp = Lpanel + (size_t)j * prow * 6;
+    double cur[2][6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) yj[k] = row[k];
-      } else {
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int k = 0; k < 6; ++k) cur[q][k] = nx[q][k];
+    const double yj = ny;
+    if (j > 0) fetch(j - 1);
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint32_t r = lane + 64 * q;
+      if (r < nrows - 1) {
         const double xv = (r < 6 * nbel) ? xs[6 * ((uint32_t)j + 1 + r / 6) + r % 6] : xs[6 * F + (r - 6 * nbel)];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) acc[k] += row[k] * xv;
+        for (int k = 0; k < 6; ++k) acc[k] += cur[q][k] * xv;
       }
     }
+    for (uint32_t r = lane + 128; r < nrows - 1; r += 64) {   // wider panels: the rows beyond the prefetched two per lane
+      const double* row = Lp + (size_t)r * 6;
+      const double xv = (r < 6 * nbel) ? xs[6 * ((uint32_t)j + 1 + r / 6) + r % 6] : xs[6 * F + (r - 6 * nbel)];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) { acc[k] = wave_sum(acc[k]); yj[k] = wave_sum(yj[k]); }
+      for (int k = 0; k < 6; ++k) acc[k] += row[k] * xv;
+    }
+    double tot[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double sdpp = wave_sum_dpp(acc[k]);   // total in lane 63
+      tot[k] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(sdpp), 63), __builtin_amdgcn_readlane(__double2loint(sdpp), 63));
+    }
+    // t = y_j - acc (lane k holds t_k), x_j = L_jj^-T t: (L^-T t)[lane] = sum_{k >= lane} Li[k][lane] t[k]
+    double tk = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) if (lane == (uint32_t)k) tk = yj - tot[k];
     if (lane < 6) {
       const double* Li = d.Linv + (size_t)j * 36;
-      double o = 0.0;   // (L^-T t)[lane] = sum_{k >= lane} Li[k][lane] t[k]
+      double o = 0.0;
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { const double tk = yj[k] - acc[k]; if (k >= (int)lane) o += Li[k * 6 + lane] * tk; }
+      for (int k = 0; k < 6; ++k) {
+        const double t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tk), k), __builtin_amdgcn_readlane(__double2loint(tk), k));
+        if (k >= (int)lane) o += Li[k * 6 + lane] * t;
+      }
       xs[6 * j + lane] = o;
     }
     __syncthreads();
