@@ -93,7 +93,7 @@ struct lifcal_ba_handle {
   bool constrained = false;
   lifcal_ba_allreduce_fn hook = nullptr; void* hook_ctx = nullptr;
   lifcal_ba_allgather_fn ghook = nullptr; void* ghook_ctx = nullptr;
-  Xch xch{}; bool xch_ok = false;   // slab exchange of the reduced block (multi-GPU, no promoted points)
+  Xch xch{}; bool xch_ok = false, force_exchange = false;   // slab exchange of the reduced block (multi-GPU, no promoted points)
   void* comm = nullptr;
   double last_cost = 0, last_gmax = 0;
   size_t chol_lds = 0;
@@ -133,7 +133,7 @@ int do_allreduce(lifcal_ba_handle* h, double* buf, size_t count) {
 
 // sum of the per-rank partial reduced blocks: slab all-gather + local add where it applies, else one sum all-reduce
 int exchange_reduced(lifcal_ba_handle* h) {
-  if (h->opt.world_size <= 1) return 0;
+  if (h->opt.world_size <= 1 && !h->force_exchange) return 0;   // (LIFCAL_FORCE_EXCHANGE: run pack / all-gather / unpack at world size 1, for tests)
   const bool have_gather = h->ghook ? (h->hook != nullptr) : (h->hook == nullptr && h->comm != nullptr);
   if (!h->xch_ok || !have_gather) return do_allreduce(h, h->red_block, h->red_count);
   const Xch& x = h->xch;
@@ -552,7 +552,8 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   d.Sband = h->red_block; d.Sarrow = d.Sband + n_band; d.rhsacc = d.Sarrow + n_arrow; d.gB = d.rhsacc + d.n_red; d.hdiag = d.gB + d.n_red; d.scal = d.hdiag + d.n_red;
   A(d.sig_red, d.n_red); A(d.lam_red, d.n_red); A(d.delta_red, d.n_red); A(d.Linv, (size_t)d.F * 36 + 36);
   // multi-GPU: slab exchange of the reduced block (every rank's partial block lives in one frame range)
-  if (opt.world_size > 1 && d.Q == 0 && d.use_poses && getenv("LIFCAL_DENSE_ALLREDUCE") == nullptr) {
+  h->force_exchange = getenv("LIFCAL_FORCE_EXCHANGE") != nullptr;
+  if ((opt.world_size > 1 || h->force_exchange) && d.Q == 0 && d.use_poses && getenv("LIFCAL_DENSE_ALLREDUCE") == nullptr) {
     Xch& x = h->xch;
     x.world = (uint32_t)opt.world_size; x.rank = (uint32_t)opt.rank; x.BS = (d.bw + 1) * 36; x.NA = d.NA; x.F6 = 6 * d.F;
     uint32_t maxn = 1;

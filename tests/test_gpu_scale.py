@@ -74,6 +74,19 @@ def test_rccl_single_rank_and_hook_paths(built):
         ba.comm_init_rccl(comm_unique_id())
         got = ba.sweep(1e4, want_matrices=True)
         assert scaled_max_err(got.S, ref.S) < 1e-9
+    # the slab exchange (pack -> ncclAllGather -> unpack) through the real RCCL communicator, forced at world size 1
+    import os
+    os.environ["LIFCAL_FORCE_EXCHANGE"] = "1"
+    try:
+        with BundleAdjustment(problem(sc), o) as ba:
+            ba.comm_init_rccl(comm_unique_id())
+            got = ba.sweep(1e4, want_matrices=True)
+            assert abs(got.cost - ref.cost) <= 1e-12 * ref.cost
+            assert scaled_max_err(got.S, ref.S) < 1e-9 and vec_err(got.rhs, ref.rhs) < 1e-9
+            s = ba.performBundleAdjustment()
+            assert s.termination in (1, 2)
+    finally:
+        del os.environ["LIFCAL_FORCE_EXCHANGE"]
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipStreamSynchronize.argtypes = [C.c_void_p]
