@@ -63,7 +63,7 @@ struct Dev {
   const uint32_t *gid_fr, *slot_gid;              // frame of each group id; v1 path: group id of each slot
   // v2 (LDS-window) path
   uint32_t n_blocks, v2_nfmax, n_special;
-  const uint32_t *blk_pass0, *blk_flo, *blk_nf, *pass_pt0, *pass_np, *pass_gid0, *pass_ng, *v2_points, *v2_ptinfo, *v2_slot, *v2_tile_row0, *v2_lens, *v2f_pt, *v2_passpt;
+  const uint32_t *blk_pass0, *blk_flo, *blk_nf, *pass_pt0, *pass_np, *pass_gid0, *pass_ng, *v2_points, *v2_ptinfo, *v2_slot, *v2_tile_row0, *v2_lens, *v2f_pt, *v2_passpt, *v2_gidx;
   const double *v2_u, *v2_v;
   const uint32_t* special_owned;
   // constraints

@@ -471,7 +471,9 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   // LIFCAL_GROUP_SPLIT: observations per lane above which a (point, frame) group is cut into several lanes
   // (0 = never; default: chosen per block by the planner's cost model)
   const uint32_t split_obs = getenv("LIFCAL_GROUP_SPLIT") ? (uint32_t)std::max(0, atoi(getenv("LIFCAL_GROUP_SPLIT"))) : UINT32_MAX;
-  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs);
+  // the wave-specialised kernel wants the lanes of a pass sorted by frame, k_sweep2 (LIFCAL_SWEEP_KERNEL=2) by point
+  h->use_sweep3 = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
+  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs, h->use_sweep3);
   if (rc) { delete h; return rc; }
   h->prob = *p;
   int ndev = 0;
@@ -516,14 +518,22 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
     U(t, L.gid_fr); d.gid_fr = t; U(t, L.slot_gid); d.slot_gid = t; U(t, L.special_owned); d.special_owned = t;
     U(t, L.blk_pass0); d.blk_pass0 = t; U(t, L.blk_flo); d.blk_flo = t; U(t, L.blk_nf); d.blk_nf = t;
     U(t, L.pass_pt0); d.pass_pt0 = t; U(t, L.pass_np); d.pass_np = t; U(t, L.pass_gid0); d.pass_gid0 = t; U(t, L.pass_ng); d.pass_ng = t;
-    U(t, L.v2_points); d.v2_points = t; U(t, L.v2_ptinfo); d.v2_ptinfo = t; U(t, L.v2_passpt); d.v2_passpt = t; U(t, L.v2_slot); d.v2_slot = t; U(t, L.v2_tile_row0); d.v2_tile_row0 = t; U(t, L.v2_lens); d.v2_lens = t; }
+    U(t, L.v2_points); d.v2_points = t; U(t, L.v2_ptinfo); d.v2_ptinfo = t; U(t, L.v2_passpt); d.v2_passpt = t; U(t, L.v2_gidx); d.v2_gidx = t; U(t, L.v2_slot); d.v2_slot = t; U(t, L.v2_tile_row0); d.v2_tile_row0 = t; U(t, L.v2_lens); d.v2_lens = t; }
   { double* t; U(t, L.v2_u); d.v2_u = t; U(t, L.v2_v); d.v2_v = t; }
   { uint32_t *a, *b, *c; U(a, L.v2f_pt); U(b, L.v2f_fr); U(c, L.v2f_cnt);
     d.v2f_pt = a;
     h->ts2 = TileSet{4 * L.n_passes, d.v2_tile_row0, a, b, c, d.v2_lens, d.v2_u, d.v2_v}; }
   d.n_blocks = L.n_blocks; d.v2_nfmax = std::max(1u, L.max_block_nf); d.n_special = (uint32_t)L.special_owned.size();
-  h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax).total * sizeof(double);
-  h->use_sweep3 = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
+  // the LDS-window kernels trust the plan: the dense Z matrix of every pass (rows rounded up to 8) must fit its LDS region
+  for (uint32_t b = 0; b < L.n_blocks; ++b) {
+    const uint32_t ncolp = ((6 * L.blk_nf[b] + (uint32_t)L.nc + 1) + 15u) & ~15u;
+    for (uint32_t ps = L.blk_pass0[b]; ps < L.blk_pass0[b + 1]; ++ps)
+      if ((size_t)((3 * L.pass_np[ps] + 7u) & ~7u) * (ncolp + 2) > ZD_DOUBLES || L.pass_ng[ps] > Plan::PASS_GROUPS || L.pass_np[ps] > Plan::NP_MAX) {
+        g_last_error = "internal: a planned pass does not fit the LDS window";
+        return fail(LIFCAL_BA_ERR_INVALID_ARG);
+      }
+  }
+  h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax, h->use_sweep3).total * sizeof(double);
   if (d.n_blocks) {
 #define SET_LDS(NR, TAN, ADJ) do { if (hipFuncSetAttribute((const void*)k_sweep2<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
     if (hipFuncSetAttribute((const void*)k_sweep3<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); } while (0)

@@ -75,6 +75,7 @@ struct Plan {
   std::vector<uint32_t> pass_pt0, pass_np, pass_gid0, pass_ng;   // per pass: first entry in v2_points, #points, first gid, #groups
   std::vector<uint32_t> v2_points;     // point ids in processing order
   std::vector<uint32_t> v2_ptinfo;     // per entry of v2_points: first pass-local group | number of groups << 16
+  std::vector<uint32_t> v2_gidx;       // per (pass*256 + wave*64 + lane): group id of the lane (index of its A block for the back-substitution)
   std::vector<uint32_t> v2_passpt;     // per (pass*64 + k): k-th point of the pass (0-padded): descriptor-free lookup for the factor phase
   std::vector<uint32_t> v2_slot;       // per (pass*256 + wave*64 + lane): cnt | lf<<8 | lp<<16 | rep<<24 ; 0 = idle
   std::vector<uint32_t> v2f_pt, v2f_fr, v2f_cnt;   // the same slots, flat (value-only kernels: cost, statistics)
@@ -108,7 +109,7 @@ inline int plan_validate(const lifcal_ba_problem* p) {
   return 0;
 }
 
-inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl, bool enable_v2 = true, uint32_t target_blocks = 256, uint32_t split_obs = UINT32_MAX) {
+inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl, bool enable_v2 = true, uint32_t target_blocks = 256, uint32_t split_obs = UINT32_MAX, bool frame_order = false) {
   if (int rc = plan_validate(p)) return rc;
   if (world < 1 || rank < 0 || rank >= world) return LIFCAL_BA_ERR_INVALID_ARG;
   Plan& L = *pl;
@@ -265,7 +266,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   auto block_np_cap = [&](size_t b) {
     // the dense Z matrix of a pass (3 np rows x padded window columns) must fit its LDS budget
     const uint32_t ncolp = ((6 * L.blk_nf[b] + (uint32_t)L.nc + 1) + 15u) & ~15u;
-    return std::max(1u, std::min<uint32_t>(Plan::NP_MAX, ((Plan::ZD_DOUBLES / (ncolp + 2)) & ~3u) / 3));
+    return std::max(1u, std::min<uint32_t>(Plan::NP_MAX, ((Plan::ZD_DOUBLES / (ncolp + 2)) & ~7u) / 3));
   };
 
   // --- lanes: a (point, frame) group of a regular point with more than T observations is cut into near-equal parts, one
@@ -408,29 +409,47 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
           const uint32_t q = L.v2_points[L.pass_pt0[ps] + k];
           for (uint32_t g = L.pt_slot0[q]; g < L.pt_slot0[q] + L.pt_nslots[q]; ++g) pass_groups[ps].push_back(g);
         }
-    for (uint32_t ps = 0; ps < L.n_passes; ++ps)
-      for (uint32_t w = 0; w < 4; ++w) {
-        uint32_t kmax = 0;
-        for (uint32_t g = w; g < pass_groups[ps].size(); g += 4) kmax = std::max(kmax, groups[pass_groups[ps][g]].n);
-        L.v2_tile_row0[(size_t)ps * 4 + w + 1] = L.v2_tile_row0[(size_t)ps * 4 + w] + kmax;
+    // lane slot of the k-th group of a pass.  Point order (k_sweep2): group k -> wave k % 4, lane k / 4, the lanes of a
+    // point sit side by side and the frame accumulators are replicated.  Frame order (k_sweep3): the pass's lanes are sorted
+    // by frame and cut into four tiles of 64, so the lanes of ONE frame sit side by side and their frame-level blocks are
+    // summed with DPP before a single lane adds them to LDS.
+    struct LaneOf { uint32_t gid, lp; };
+    std::vector<std::vector<LaneOf>> lanes(L.n_passes);
+    for (uint32_t ps = 0; ps < L.n_passes; ++ps) {
+      uint32_t lp = 0, left = 0;
+      for (uint32_t k = 0; k < pass_groups[ps].size(); ++k) {
+        const Group& G = groups[pass_groups[ps][k]];
+        if (k == 0) { lp = 0; left = L.pt_nslots[G.pt]; }
+        else if (left == 0) { ++lp; left = L.pt_nslots[G.pt]; }
+        --left;
+        lanes[ps].push_back({pass_groups[ps][k], lp});
       }
+      if (frame_order)
+        std::stable_sort(lanes[ps].begin(), lanes[ps].end(), [&](const LaneOf& x, const LaneOf& y) { return groups[x.gid].fr < groups[y.gid].fr; });
+    }
+    auto slot_of = [&](uint32_t k, uint32_t& w, uint32_t& l) { if (frame_order) { w = k / 64; l = k % 64; } else { w = k % 4; l = k / 4; } };
+    for (uint32_t ps = 0; ps < L.n_passes; ++ps) {
+      uint32_t kmax[4] = {0, 0, 0, 0};
+      for (uint32_t k = 0; k < lanes[ps].size(); ++k) { uint32_t w, l; slot_of(k, w, l); kmax[w] = std::max(kmax[w], groups[lanes[ps][k].gid].n); }
+      for (uint32_t w = 0; w < 4; ++w) L.v2_tile_row0[(size_t)ps * 4 + w + 1] = L.v2_tile_row0[(size_t)ps * 4 + w] + kmax[w];
+    }
     const size_t rows = L.v2_tile_row0[(size_t)L.n_passes * 4];
     L.v2_u.assign(rows * 64, 0.0); L.v2_v.assign(rows * 64, 0.0); L.v2_lens.assign(rows * 64, 0); L.v2_src.assign(rows * 64, UINT32_MAX);
+    L.v2_gidx.assign((size_t)L.n_passes * 256, 0);
     for (uint32_t b = 0; b < L.n_blocks; ++b)
       for (uint32_t ps = L.blk_pass0[b]; ps < L.blk_pass0[b + 1]; ++ps) {
-        // local point index of each group; replica = occurrence rank of the group's frame inside its wave
-        uint32_t lp = 0, left = 0;
+        // replica = occurrence rank of the lane's frame inside its wave (point order only: k_sweep2's replicated accumulators)
         std::vector<uint32_t> occ(4 * (Plan::NF_MAX + 1), 0);
-        for (uint32_t g = 0; g < pass_groups[ps].size(); ++g) {
-          const Group& G = groups[pass_groups[ps][g]];
-          if (g == 0) { lp = 0; left = L.pt_nslots[G.pt]; }
-          else if (left == 0) { ++lp; left = L.pt_nslots[G.pt]; }
-          --left;
-          const uint32_t w = g % 4, l = g / 4;
+        for (uint32_t k = 0; k < lanes[ps].size(); ++k) {
+          const Group& G = groups[lanes[ps][k].gid];
+          const uint32_t lp = lanes[ps][k].lp;
+          uint32_t w, l; slot_of(k, w, l);
           const uint32_t lfl = G.fr - L.blk_flo[b];
           const uint32_t rep = std::min(255u, occ[w * (Plan::NF_MAX + 1) + lfl]++);
-          L.v2_slot[(size_t)ps * 256 + w * 64 + l] = std::min(G.n, 255u) | (lfl << 8) | (lp << 16) | (rep << 24);
-          L.v2f_pt[(size_t)ps * 256 + w * 64 + l] = G.pt; L.v2f_fr[(size_t)ps * 256 + w * 64 + l] = G.fr; L.v2f_cnt[(size_t)ps * 256 + w * 64 + l] = G.n;
+          const size_t at_slot = (size_t)ps * 256 + w * 64 + l;
+          L.v2_slot[at_slot] = std::min(G.n, 255u) | (lfl << 8) | (lp << 16) | (rep << 24);
+          L.v2f_pt[at_slot] = G.pt; L.v2f_fr[at_slot] = G.fr; L.v2f_cnt[at_slot] = G.n;
+          L.v2_gidx[at_slot] = lanes[ps][k].gid;
           for (uint32_t j = 0; j < G.n; ++j) {
             const size_t at = ((size_t)L.v2_tile_row0[(size_t)ps * 4 + w] + j) * 64 + l;
             const uint32_t i = L.obs_order[G.s0 + j];

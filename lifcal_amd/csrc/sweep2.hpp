@@ -26,20 +26,26 @@ constexpr uint32_t FRV = 27 + 6 * NCMAX;   // frame-level values a group emits: 
 constexpr uint32_t LDS_LIMIT_DOUBLES = 160 * 1024 / 8;
 
 struct V2Lds {
-  uint32_t nfm, nrep, off_cp, off_cc, off_vec, off_fr, off_slab, off_zd, off_misc, total;
-  __host__ __device__ explicit V2Lds(uint32_t nfmax) {
+  uint32_t nfm, nrep, off_cp, off_cc, off_vec, off_fr, off_bt, off_slab, off_zd, off_misc, total;
+  // single_replica: k_sweep3 (lanes sorted by frame, frame-level values pre-summed over runs of lanes): one set of frame
+  // accumulators; the LDS this frees holds the accumulator threads' partial Schur tiles (16 doubles x 256 threads) when they fit
+  __host__ __device__ explicit V2Lds(uint32_t nfmax, bool single_replica = false) {
     nfm = nfmax;
     const uint32_t npp = nfm * (nfm + 1) / 2;
     off_cp = npp * 36; off_cc = off_cp + NCMAX * 6 * nfm; off_vec = off_cc + 48;
     off_fr = off_vec + 3 * (6 * nfm + NCMAX + 3);
     off_fr = (off_fr + 1) & ~1u;
-    // replicated frame accumulators [rep][value][frame]: as many replicas (<= 8) as the 160 KiB LDS allows
+    // replicated frame accumulators [value][rep][frame]: as many replicas (<= 8) as the 160 KiB LDS allows
     const uint32_t fixed = off_fr + 64 * 12 + ZD_DOUBLES + 8 + 32 + 64;
     uint32_t r = (LDS_LIMIT_DOUBLES - fixed) / (FRV * nfm);
-    nrep = r < 1 ? 1 : (r > 8 ? 8 : r);
-    off_slab = off_fr + nrep * FRV * nfm;
+    nrep = single_replica ? 1u : (r < 1 ? 1 : (r > 8 ? 8 : r));
+    off_bt = off_fr + nrep * FRV * nfm;
+    off_bt = (off_bt + 1) & ~1u;
+    const bool bt = single_replica && (off_bt + 16 * 256 + 64 * 12 + ZD_DOUBLES + 8 + 32 + 64 <= LDS_LIMIT_DOUBLES);
+    off_slab = off_bt + (bt ? 16 * 256 : 0);
     off_zd = off_slab + 64 * 12; off_misc = off_zd + ZD_DOUBLES; total = off_misc + 8 + 32 + 64;   // misc(8) | point ids (64 u32) | column info (<= 256 u16)
   }
+  __host__ __device__ bool has_bt() const { return off_slab != off_bt; }
 };
 
 typedef double v4f64 __attribute__((ext_vector_type(4)));
@@ -356,7 +362,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
         }
         if (mode == 0) {
           // only A goes to HBM for the back-substitution (48 B per lane): k_backsub rebuilds W_pose = R^T A [Gr | I] from it
-          { double* ga = d.Av + (size_t)(gid0 + g) * 6;
+          { double* ga = d.Av + (size_t)d.v2_gidx[(size_t)ps * 256 + tid] * 6;
 #pragma unroll
             for (int k = 0; k < 6; ++k) ga[k] = A[k]; }
 #pragma unroll

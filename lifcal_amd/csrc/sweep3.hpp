@@ -25,7 +25,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
   constexpr int HV = 6 + 2 * NC + 2;   // doubles handed over per lane and step: Jq (6) | Jc (2 NC) | r (2)
   static_assert(HV * 256 <= (int)ZD_DOUBLES, "hand-off buffer must fit the Z matrix");
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const V2Lds lay(d.v2_nfmax);
+  const V2Lds lay(d.v2_nfmax, true);
   const uint32_t NFm = lay.nfm, vlen = 6 * NFm + NCMAX + 3;
   double* Spp = sm; double* Scp = sm + lay.off_cp; double* Scc = sm + lay.off_cc;
   double* vgB = sm + lay.off_vec; double* vhd = vgB + vlen; double* vrhs = vhd + vlen;
@@ -53,12 +53,12 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
 #endif
   // pass descriptors and per-lane slot words, one pass ahead (see k_sweep2)
   const uint32_t ps_begin = d.blk_pass0[b], ps_end = d.blk_pass0[b + 1];
-  uint32_t nx_np = 0, nx_gid0 = 0, nx_si = 0, nx_pt = 0, nx_fp = 0, nx_r[2] = {0, 0};
+  uint32_t nx_np = 0, nx_gid0 = 0, nx_si = 0, nx_pt = 0, nx_fp = 0, nx_gid = 0, nx_r[2] = {0, 0};
   uint32_t vz;
   asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
   auto fetch_pass = [&](uint32_t q) {
     nx_np = d.pass_np[q + vz]; nx_gid0 = d.pass_gid0[q + vz];
-    nx_si = d.v2_slot[(size_t)q * 256 + t256]; nx_pt = d.v2f_pt[(size_t)q * 256 + t256];
+    nx_si = d.v2_slot[(size_t)q * 256 + t256]; nx_pt = d.v2f_pt[(size_t)q * 256 + t256]; nx_gid = d.v2_gidx[(size_t)q * 256 + t256];
     nx_r[0] = d.v2_tile_row0[q * 4 + wl + vz]; nx_r[1] = d.v2_tile_row0[q * 4 + wl + 1 + vz];   // observation rows of the wave's tile
     nx_fp = d.v2_passpt[(size_t)q * 64 + (tid & 63u)];
   };
@@ -109,7 +109,34 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
     q.Gr[1][0] = -q.Y[2]; q.Gr[1][1] = s0 * q.Y[0];               q.Gr[1][2] = n2 * q.Y[0] - n0 * q.Y[2];
     q.Gr[2][0] = q.Y[1];  q.Gr[2][1] = -c0 * q.Y[0];              q.Gr[2][2] = n0 * q.Y[1] - n1 * q.Y[0];
   };
-  const uint32_t frs = NFm * lay.nrep;   // stride between values of the replicated frame accumulators
+  const uint32_t frs = NFm * lay.nrep;   // stride between the values of the frame accumulators (replica 0 is the only one used here)
+  // The lanes of a pass are sorted by frame (plan.hpp, frame order): the lanes of one frame form runs inside each row of 16
+  // lanes.  Frame-level values are summed over a run with four masked DPP row shifts (lane i += lane i+n if that lane
+  // belongs to the same frame), and only the first lane of a run adds the total to LDS: ~7 lanes per wave instruction on
+  // distinct addresses instead of 64 lanes with bank and same-address conflicts.
+  struct RunMask { double m1, m2, m4, m8; bool head; };
+  auto run_masks = [&](uint32_t cnt, uint32_t lf) {
+    const int key = cnt > 0 ? (int)lf : (int)(0x7F000000u + lane);   // idle lanes never match
+    RunMask r;
+    r.m1 = __builtin_amdgcn_update_dpp(-1, key, 0x101, 0xf, 0xf, false) == key ? 1.0 : 0.0;   // row_shl:1 (lane i reads lane i+1 of its row)
+    r.m2 = __builtin_amdgcn_update_dpp(-1, key, 0x102, 0xf, 0xf, false) == key ? 1.0 : 0.0;
+    r.m4 = __builtin_amdgcn_update_dpp(-1, key, 0x104, 0xf, 0xf, false) == key ? 1.0 : 0.0;
+    r.m8 = __builtin_amdgcn_update_dpp(-1, key, 0x108, 0xf, 0xf, false) == key ? 1.0 : 0.0;
+    r.head = cnt > 0 && __builtin_amdgcn_update_dpp(-1, key, 0x111, 0xf, 0xf, false) != key;   // row_shr:1: the previous lane of the row
+    return r;
+  };
+  auto run_sum = [](double v, const RunMask& r) {
+    auto shl = [](double x, auto ctrl) {
+      const int lo = __double2loint(x), hi = __double2hiint(x);
+      return __hiloint2double(__builtin_amdgcn_update_dpp(0, hi, decltype(ctrl)::value, 0xf, 0xf, true),
+                              __builtin_amdgcn_update_dpp(0, lo, decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v = fma(shl(v, std::integral_constant<int, 0x101>{}), r.m1, v);
+    v = fma(shl(v, std::integral_constant<int, 0x102>{}), r.m2, v);
+    v = fma(shl(v, std::integral_constant<int, 0x104>{}), r.m4, v);
+    v = fma(shl(v, std::integral_constant<int, 0x108>{}), r.m8, v);
+    return v;
+  };
   // hand-off counters of the wave pair (evaluator wl, accumulator wl + 4): monotone over the whole kernel, zeroed with misc
   uint32_t* hw_written = (uint32_t*)(misc + 4) + wl;       // steps the evaluator has published
   uint32_t* hw_read = (uint32_t*)(misc + 4) + 4 + wl;      // steps the accumulator has taken
@@ -122,6 +149,81 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
     __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
 
+  // Schur product: 4x4 micro-tiles over the lower triangle, software-pipelined.  With one tile per thread (ntri <= 256) the
+  // evaluator thread keeps its tile in registers across the passes, and the K dimension is split between the roles: evaluator
+  // thread t takes rows 0-3 of every 8, accumulator thread 256 + t rows 4-7, its partial tile living in LDS between passes
+  // (the accumulators have no registers to spare; the single set of frame accumulators leaves the room).
+  const uint32_t nmt = (ncol + 3u) >> 2, ntri = nmt * (nmt + 1) / 2;
+  auto tri_decode = [](uint32_t t, uint32_t& mi, uint32_t& mj) {
+    mi = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (mi * (mi + 1) / 2 > t) --mi;
+    while ((mi + 1) * (mi + 2) / 2 <= t) ++mi;
+    mj = t - mi * (mi + 1) / 2;
+  };
+  auto gemm_tile = [&](uint32_t mi, uint32_t mj, uint32_t kfirst, uint32_t kstep, uint32_t krows, double (&acc16)[4][4]) {
+    const double* za = Zd + 4 * mi;
+    const double* zb = Zd + 4 * mj;
+    double2 cur[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      cur[r][0] = *reinterpret_cast<const double2*>(za + (size_t)(kfirst + r) * zs);
+      cur[r][1] = *reinterpret_cast<const double2*>(za + (size_t)(kfirst + r) * zs + 2);
+      cur[r][2] = *reinterpret_cast<const double2*>(zb + (size_t)(kfirst + r) * zs);
+      cur[r][3] = *reinterpret_cast<const double2*>(zb + (size_t)(kfirst + r) * zs + 2);
+    }
+#pragma unroll 2
+    for (uint32_t k0 = kfirst; k0 < krows; k0 += kstep) {
+      double2 nxt[4][4];
+      const uint32_t kn = (k0 + kstep < krows) ? k0 + kstep : k0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        nxt[r][0] = *reinterpret_cast<const double2*>(za + (size_t)(kn + r) * zs);
+        nxt[r][1] = *reinterpret_cast<const double2*>(za + (size_t)(kn + r) * zs + 2);
+        nxt[r][2] = *reinterpret_cast<const double2*>(zb + (size_t)(kn + r) * zs);
+        nxt[r][3] = *reinterpret_cast<const double2*>(zb + (size_t)(kn + r) * zs + 2);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double av[4] = {cur[r][0].x, cur[r][0].y, cur[r][1].x, cur[r][1].y};
+        const double bq[4] = {cur[r][2].x, cur[r][2].y, cur[r][3].x, cur[r][3].y};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc16[i][j] += av[i] * bq[j];
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) cur[r][q] = nxt[r][q];
+    }
+  };
+  auto emit_tile = [&](uint32_t mi, uint32_t mj, const double (&acc16)[4][4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t ci = 4 * mi + i;
+      const uint32_t ii = colinfo[ci < ncolp ? ci : 0];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t cj = 4 * mj + j;
+        const double dv = acc16[i][j];
+        if (ci >= ncol || cj >= ncol || ci < cj) continue;
+        const uint32_t jj = colinfo[cj];
+        if (!(ii & 0x8000u)) {            // pose x pose
+          const uint32_t lfi = ii >> 8, lfj = jj >> 8;
+          Spp[(size_t)(lfi * (lfi + 1) / 2 + lfj) * 36 + (ii & 0xFFu) * 6 + (jj & 0xFFu)] -= dv;
+        } else if (!(ii & 0x4000u)) {     // camera row
+          const uint32_t jc = ii & 0xFFu;
+          if (!(jj & 0x8000u)) Scp[(size_t)jc * 6 * NFm + cj] -= dv;
+          else Scc[jc * (jc + 1) / 2 + (jj & 0xFFu)] -= dv;
+        } else if (cj < ncol - 1) {       // rhs row: W^T U^-1 g
+          if (!(jj & 0x8000u)) vrhs[cj] += dv; else vrhs[6 * NFm + (jj & 0xFFu)] += dv;
+        }
+      }
+    }
+  };
+  const bool keep_tiles = (mode == 0) && ntri <= 256;
+  const bool ksplit = keep_tiles && lay.has_bt();
+  double* bt = sm + lay.off_bt;   // [16][256] partial tiles of the accumulator threads
   if (!role_b) {
     // =====================================================================================================================
     // evaluator waves (threads 0..255)
@@ -129,76 +231,6 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
     double cost = 0.0, lmant = 1.0; int lexp = 0;
     uint32_t hbase = 0;   // steps of the passes before this one (hand-off counters are monotone)
     uint32_t passes_done = 0;
-    // Schur product: 4x4 micro-tiles over the lower triangle, software-pipelined, tiles kept in registers across passes
-    const uint32_t nmt = (ncol + 3u) >> 2, ntri = nmt * (nmt + 1) / 2;
-    auto tri_decode = [](uint32_t t, uint32_t& mi, uint32_t& mj) {
-      mi = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while (mi * (mi + 1) / 2 > t) --mi;
-      while ((mi + 1) * (mi + 2) / 2 <= t) ++mi;
-      mj = t - mi * (mi + 1) / 2;
-    };
-    auto gemm_tile = [&](uint32_t mi, uint32_t mj, uint32_t krows, double (&acc16)[4][4]) {
-      const double* za = Zd + 4 * mi;
-      const double* zb = Zd + 4 * mj;
-      double2 cur[4][4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        cur[r][0] = *reinterpret_cast<const double2*>(za + (size_t)r * zs);
-        cur[r][1] = *reinterpret_cast<const double2*>(za + (size_t)r * zs + 2);
-        cur[r][2] = *reinterpret_cast<const double2*>(zb + (size_t)r * zs);
-        cur[r][3] = *reinterpret_cast<const double2*>(zb + (size_t)r * zs + 2);
-      }
-#pragma unroll 2
-      for (uint32_t k0 = 0; k0 < krows; k0 += 4) {
-        double2 nxt[4][4];
-        const uint32_t kn = (k0 + 4 < krows) ? k0 + 4 : k0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          nxt[r][0] = *reinterpret_cast<const double2*>(za + (size_t)(kn + r) * zs);
-          nxt[r][1] = *reinterpret_cast<const double2*>(za + (size_t)(kn + r) * zs + 2);
-          nxt[r][2] = *reinterpret_cast<const double2*>(zb + (size_t)(kn + r) * zs);
-          nxt[r][3] = *reinterpret_cast<const double2*>(zb + (size_t)(kn + r) * zs + 2);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const double av[4] = {cur[r][0].x, cur[r][0].y, cur[r][1].x, cur[r][1].y};
-          const double bq[4] = {cur[r][2].x, cur[r][2].y, cur[r][3].x, cur[r][3].y};
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc16[i][j] += av[i] * bq[j];
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int q = 0; q < 4; ++q) cur[r][q] = nxt[r][q];
-      }
-    };
-    auto emit_tile = [&](uint32_t mi, uint32_t mj, const double (&acc16)[4][4]) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const uint32_t ci = 4 * mi + i;
-        const uint32_t ii = colinfo[ci < ncolp ? ci : 0];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t cj = 4 * mj + j;
-          const double dv = acc16[i][j];
-          if (ci >= ncol || cj >= ncol || ci < cj) continue;
-          const uint32_t jj = colinfo[cj];
-          if (!(ii & 0x8000u)) {            // pose x pose
-            const uint32_t lfi = ii >> 8, lfj = jj >> 8;
-            Spp[(size_t)(lfi * (lfi + 1) / 2 + lfj) * 36 + (ii & 0xFFu) * 6 + (jj & 0xFFu)] -= dv;
-          } else if (!(ii & 0x4000u)) {     // camera row
-            const uint32_t jc = ii & 0xFFu;
-            if (!(jj & 0x8000u)) Scp[(size_t)jc * 6 * NFm + cj] -= dv;
-            else Scc[jc * (jc + 1) / 2 + (jj & 0xFFu)] -= dv;
-          } else if (cj < ncol - 1) {       // rhs row: W^T U^-1 g
-            if (!(jj & 0x8000u)) vrhs[cj] += dv; else vrhs[6 * NFm + (jj & 0xFFu)] += dv;
-          }
-        }
-      }
-    };
-    const bool keep_tiles = (mode == 0) && ntri <= 256;
     uint32_t mi0 = 0, mj0 = 0;
     if (keep_tiles && tid < ntri) tri_decode(tid, mi0, mj0);
     double tacc[4][4];
@@ -210,12 +242,12 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
     STAMP(14);
     for (uint32_t ps = ps_begin; ps < ps_end; ++ps) {
       const uint32_t np = __builtin_amdgcn_readfirstlane(nx_np), gid0 = __builtin_amdgcn_readfirstlane(nx_gid0);
-      const uint32_t si = nx_si, pt = nx_pt, fp = nx_fp;
+      const uint32_t si = nx_si, pt = nx_pt, fp = nx_fp, gidx = nx_gid;
       const uint32_t row0 = __builtin_amdgcn_readfirstlane(nx_r[0]), kmax = __builtin_amdgcn_readfirstlane(nx_r[1]) - row0;
       double fsg0 = 1.0, fsg1 = 1.0, fsg2 = 1.0;
       if (mode == 0 && tid < np) { fsg0 = d.sigP[3 * (size_t)fp]; fsg1 = d.sigP[3 * (size_t)fp + 1]; fsg2 = d.sigP[3 * (size_t)fp + 2]; }
       if (ps + 1 < ps_end) fetch_pass(ps + 1);
-      const uint32_t krows = (3 * np + 3u) & ~3u;
+      const uint32_t krows = (3 * np + 7u) & ~7u;   // K of the product: multiple of 8 (two row groups of 4, one per role)
       STAMP(12);
       zero_slab();
       STAMP(13);
@@ -305,7 +337,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       // rotation, rotated point, d(R P)/d(angles): read again here instead of being carried through the loop (42 registers)
       LaneGeom q;
       { uint32_t fr2 = fr, pt2 = pt; asm volatile("" : "+v"(fr2), "+v"(pt2)); lane_geom(fr2, pt2, q); }
-      asm volatile("" :: "v"(nx_si), "v"(nx_pt), "v"(nx_fp), "v"(nx_np), "v"(nx_gid0), "v"(nx_r[0]), "v"(nx_r[1]));
+      asm volatile("" :: "v"(nx_si), "v"(nx_pt), "v"(nx_fp), "v"(nx_np), "v"(nx_gid0), "v"(nx_gid), "v"(nx_r[0]), "v"(nx_r[1]));
       asm volatile("" :: "v"(fsg0), "v"(fsg1), "v"(fsg2));
       STAMP(7);
       lds_barrier();                                                                                    // ---- barrier P2a: every accumulator has taken its last step
@@ -323,7 +355,9 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < 3; ++j) GAG[i][j] = Gr[0][i] * AG[0][j] + Gr[1][i] * AG[1][j] + Gr[2][i] * AG[2][j];
-        double* fr_acc = Fr + (size_t)rep * NFm + lf;   // replica-major: the lanes of a wave instruction land on one compact run of doubles
+        (void)rep;
+        const RunMask rm = run_masks(cnt, lf);
+        double* fr_acc = Fr + lf;
         {
           int vi = 0;
 #pragma unroll
@@ -332,13 +366,14 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
             for (int bb = 0; bb <= a; ++bb) {
               double v;
               if (a < 3) v = GAG[a][bb]; else if (bb < 3) v = AG[a - 3][bb]; else v = Am[a - 3][bb - 3];
-              atomicAdd(fr_acc + (size_t)vi * frs, v);
+              v = run_sum(v, rm);
+              if (rm.head) atomicAdd(fr_acc + (size_t)vi * frs, v);
               ++vi;
             }
 #pragma unroll
-          for (int a = 0; a < 3; ++a) atomicAdd(fr_acc + (size_t)(21 + a) * frs, Gr[0][a] * bv[0] + Gr[1][a] * bv[1] + Gr[2][a] * bv[2]);
+          for (int a = 0; a < 3; ++a) { const double v = run_sum(Gr[0][a] * bv[0] + Gr[1][a] * bv[1] + Gr[2][a] * bv[2], rm); if (rm.head) atomicAdd(fr_acc + (size_t)(21 + a) * frs, v); }
 #pragma unroll
-          for (int a = 0; a < 3; ++a) atomicAdd(fr_acc + (size_t)(24 + a) * frs, bv[a]);
+          for (int a = 0; a < 3; ++a) { const double v = run_sum(bv[a], rm); if (rm.head) atomicAdd(fr_acc + (size_t)(24 + a) * frs, v); }
         }
         double AR[3][3];
 #pragma unroll
@@ -356,7 +391,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
           }
         }
         if (mode == 0) {
-          { double* ga = d.Av + (size_t)(gid0 + g) * 6;
+          { double* ga = d.Av + (size_t)gidx * 6;
 #pragma unroll
             for (int k = 0; k < 6; ++k) ga[k] = A[k]; }
 #pragma unroll
@@ -428,7 +463,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
         lds_barrier();                                                                                  // ---- barrier P5
         STAMP(3);
         if (keep_tiles) {
-          if (tid < ntri) gemm_tile(mi0, mj0, krows, tacc);
+          if (tid < ntri) gemm_tile(mi0, mj0, 0, ksplit ? 8u : 4u, krows, tacc);
         } else {
           for (uint32_t t = tid; t < ntri; t += 256) {
             uint32_t mi, mj; tri_decode(t, mi, mj);
@@ -437,7 +472,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
             for (int i = 0; i < 4; ++i)
 #pragma unroll
               for (int j = 0; j < 4; ++j) acc16[i][j] = 0.0;
-            gemm_tile(mi, mj, krows, acc16);
+            gemm_tile(mi, mj, 0, 4, krows, acc16);
             emit_tile(mi, mj, acc16);
           }
         }
@@ -446,7 +481,15 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       STAMP(4);
     }
     STAMP(8);
-    if (keep_tiles && tid < ntri) emit_tile(mi0, mj0, tacc);
+    if (keep_tiles && tid < ntri) {
+      if (ksplit) {   // the accumulator thread's partial tile (complete: barrier P6 of the last pass)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) tacc[i][j] += bt[(i * 4 + j) * 256 + tid];
+      }
+      emit_tile(mi0, mj0, tacc);
+    }
     STAMP(9);
     if (d.robust) cost += 0.5 * c.loss_b * (log(lmant) + (double)lexp * 0.6931471805599453);
     cost = wave_sum_dpp(cost);
@@ -470,7 +513,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       const uint32_t si = nx_si, pt = nx_pt;
       const uint32_t kmax = __builtin_amdgcn_readfirstlane(nx_r[1]) - __builtin_amdgcn_readfirstlane(nx_r[0]);
       if (ps + 1 < ps_end) fetch_pass(ps + 1);
-      const uint32_t krows = (3 * np + 3u) & ~3u;
+      const uint32_t krows = (3 * np + 7u) & ~7u;   // K of the product: multiple of 8 (two row groups of 4, one per role)
       zero_slab();
       lds_barrier();                                                                                    // ---- barrier P1
       STAMPB(0);
@@ -529,13 +572,15 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < NC; ++j) C[i][j] *= c.chm[j];   // sign/scale folding and free-column mask, once per lane
-        double* fr_acc = Fr + (size_t)rep * NFm + lf;   // replica-major: the lanes of a wave instruction land on one compact run of doubles
+        (void)rep;
+        const RunMask rm = run_masks(cnt, lf);
+        double* fr_acc = Fr + lf;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {
 #pragma unroll
-          for (int ci = 0; ci < 3; ++ci) atomicAdd(fr_acc + (size_t)(27 + j * 6 + ci) * frs, C[0][j] * Gr[0][ci] + C[1][j] * Gr[1][ci] + C[2][j] * Gr[2][ci]);
+          for (int ci = 0; ci < 3; ++ci) { const double v = run_sum(C[0][j] * Gr[0][ci] + C[1][j] * Gr[1][ci] + C[2][j] * Gr[2][ci], rm); if (rm.head) atomicAdd(fr_acc + (size_t)(27 + j * 6 + ci) * frs, v); }
 #pragma unroll
-          for (int ci = 0; ci < 3; ++ci) atomicAdd(fr_acc + (size_t)(27 + j * 6 + 3 + ci) * frs, C[ci][j]);
+          for (int ci = 0; ci < 3; ++ci) { const double v = run_sum(C[ci][j], rm); if (rm.head) atomicAdd(fr_acc + (size_t)(27 + j * 6 + 3 + ci) * frs, v); }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -551,7 +596,20 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
         z_phase(np);
         lds_barrier();                                                                                  // ---- barrier P5
       }
-      lds_barrier();                                                                                    // ---- barrier P6 (Schur product runs on the evaluator waves)
+      if (ksplit && t256 < ntri) {   // rows 4-7 of every 8 of the Schur product; the partial tile lives in LDS between passes
+        uint32_t mi, mj; tri_decode(t256, mi, mj);
+        double acc16[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc16[i][j] = bt[(i * 4 + j) * 256 + t256];
+        gemm_tile(mi, mj, 4, 8, krows, acc16);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bt[(i * 4 + j) * 256 + t256] = acc16[i][j];
+      }
+      lds_barrier();                                                                                    // ---- barrier P6
       STAMPB(5);
     }
     {  // sign/scale folding for the thread's camera x camera block and camera gradient
