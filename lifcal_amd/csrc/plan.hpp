@@ -16,6 +16,8 @@
 //     the reduced system so that the eliminated point blocks stay independent.
 // Pure host C++ (no HIP), so the CPU test-suite can exercise it through lifcal_ba_plan().
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
@@ -279,7 +281,9 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   {
     std::vector<uint32_t> split_of(L.P, 0);   // 0 = leave the point's groups whole
     auto parts_of = [](uint32_t n, uint32_t T) { return T ? (n + T - 1) / T : 1u; };
-    constexpr double C_STEP = 4700.0, C_PASS = 21500.0, C_LANE = 65.0;   // cycles per observation step of a pass, per pass, per lane
+    // cycles per observation step of a pass, per pass, per lane (LIFCAL_PLAN_COST="step,pass,lane" overrides: tuning aid)
+    double C_STEP = 4700.0, C_PASS = 21500.0, C_LANE = 65.0;
+    if (const char* e = getenv("LIFCAL_PLAN_COST")) { double a, b2, c2; if (sscanf(e, "%lf,%lf,%lf", &a, &b2, &c2) == 3) { C_STEP = a; C_PASS = b2; C_LANE = c2; } }
     for (size_t b = 0; b + 1 < blk_begin.size(); ++b) {
       const uint32_t np_cap = block_np_cap(b);
       const size_t i0 = blk_begin[b], n = blk_begin[b + 1] - i0;
