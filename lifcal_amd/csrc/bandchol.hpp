@@ -16,10 +16,11 @@
 namespace lifcal {
 
 struct BandLds {
-  uint32_t nw, off_pn, off_d, off_map, total;   // window | panel (nw x 6) | L_jj, L_jj^-1, flag | window row of each panel row
+  uint32_t nw, nr4, off_pn, off_d, off_map, total;   // window | panel, component-major (6 x nr4) | L_jj, L_jj^-1, flag | window row of each panel row
   __host__ __device__ BandLds(uint32_t bw, uint32_t NA) {
     nw = 6 * (bw + 1) + NA + 1;
-    off_pn = nw * nw; off_d = off_pn + nw * 6; off_map = off_d + 80; total = off_map + (nw + 1) / 2 + 1;
+    nr4 = (nw + 3u) & ~3u;
+    off_pn = (nw * nw + 1u) & ~1u; off_d = off_pn + nr4 * 6; off_map = off_d + 80; total = off_map + (nr4 + 1) / 2 + 1;
   }
 };
 
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
   extern __shared__ __attribute__((aligned(16))) double bl[];
   const uint32_t F = d.F, bw = d.bw, NAx = d.NA + 1, ld = d.ld, R = bw + 1;
   const BandLds lay(bw, d.NA);
-  const uint32_t nw = lay.nw, arow0 = 6 * R;
+  const uint32_t nw = lay.nw, arow0 = 6 * R, NR = lay.nr4;
   double* Wd = bl; double* Pn = bl + lay.off_pn; double* Ld = bl + lay.off_d; double* Li = Ld + 36; double* failp = Ld + 72;
   const uint32_t lane = threadIdx.x;   // 256 threads
   uint32_t* wmap = (uint32_t*)(bl + lay.off_map);
@@ -55,49 +56,79 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
     if (b <= a) Wd[(size_t)(arow0 + a) * nw + arow0 + b] = d.Sarrow[(size_t)a * ld + 6 * F + b];
   }
   __syncthreads();
-  // ---- the chain over the pose blocks ----
-  for (uint32_t j = 0; j < F; ++j) {
-    const uint32_t sj = slot(j);
-    if (lane == 0) {   // 6x6 Cholesky and the inverse of its factor
-      // One lane, a pure dependency chain: reciprocal square roots only (v_rsq_f64 + Newton steps) — the sqrt + divide
-      // pairs of the textbook form were most of the time of a chain step.  ir[c] = 1 / L[c][c].
-      double L[6][6], ir[6];
-      for (int a = 0; a < 6; ++a) for (int b = 0; b <= a; ++b) L[a][b] = Wd[(size_t)(sj + a) * nw + sj + b];
-      bool ok = true;
+  // 6x6 Cholesky of pose block jf and the inverse of its factor: ONE lane, a pure dependency chain
+  auto factor_block = [&](uint32_t jf, bool subtract_panel) {
+    const uint32_t sf = slot(jf);
+    // One lane, a pure dependency chain: reciprocal square roots only (v_rsq_f64 + Newton steps) — the sqrt + divide
+    // pairs of the textbook form were most of the time of a chain step.  ir[c] = 1 / L[c][c].
+    double L[6][6], ir[6];
 #pragma unroll
-      for (int cI = 0; cI < 6; ++cI) {
-        double dg = L[cI][cI];
+    for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int k = 0; k < cI; ++k) dg -= L[cI][k] * L[cI][k];
-        if (!(dg > 0.0)) { ok = false; dg = 1.0; }
-        const double idg = rsqrt(dg);
-        ir[cI] = idg; L[cI][cI] = dg * idg;
+      for (int b = 0; b <= a; ++b) L[a][b] = Wd[(size_t)(sf + a) * nw + sf + b];
+    if (subtract_panel) {   // last contribution to this block: the first six rows of the current column's panel (all loads first)
+      double P6[6][6];
 #pragma unroll
-        for (int r = cI + 1; r < 6; ++r) { double s = L[r][cI];
+      for (int k = 0; k < 6; ++k)
 #pragma unroll
-          for (int k = 0; k < cI; ++k) s -= L[r][k] * L[cI][k];
-          L[r][cI] = s * idg; }
-      }
-      if (!ok) *failp = 1.0;
-      double I[6][6];
-#pragma unroll
-      for (int cI = 0; cI < 6; ++cI) {
-#pragma unroll
-        for (int r = 0; r < 6; ++r) I[r][cI] = 0.0;
-        I[cI][cI] = ir[cI];
-#pragma unroll
-        for (int r = cI + 1; r < 6; ++r) { double s = 0.0;
-#pragma unroll
-          for (int k = cI; k < r; ++k) s -= L[r][k] * I[k][cI];
-          I[r][cI] = s * ir[r]; }
-      }
+        for (int a = 0; a < 6; ++a) P6[k][a] = Pn[(size_t)k * NR + a];
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
-        for (int b = 0; b < 6; ++b) { Li[a * 6 + b] = (b <= a) ? I[a][b] : 0.0; }
-      for (int k = 0; k < 36; ++k) d.Linv[(size_t)j * 36 + k] = Li[k];
+        for (int b = 0; b <= a; ++b) {
+#pragma unroll
+          for (int k = 0; k < 6; ++k) L[a][b] -= P6[k][a] * P6[k][b];
+        }
     }
+    bool ok = true;
+#pragma unroll
+    for (int cI = 0; cI < 6; ++cI) {
+      double dg = L[cI][cI];
+#pragma unroll
+      for (int k = 0; k < cI; ++k) dg -= L[cI][k] * L[cI][k];
+      if (!(dg > 0.0)) { ok = false; dg = 1.0; }
+      const double idg = rsqrt(dg);
+      ir[cI] = idg; L[cI][cI] = dg * idg;
+#pragma unroll
+      for (int r = cI + 1; r < 6; ++r) { double s = L[r][cI];
+#pragma unroll
+        for (int k = 0; k < cI; ++k) s -= L[r][k] * L[cI][k];
+        L[r][cI] = s * idg; }
+    }
+    if (!ok) *failp = 1.0;
+    double I[6][6];
+#pragma unroll
+    for (int cI = 0; cI < 6; ++cI) {
+#pragma unroll
+      for (int r = 0; r < 6; ++r) I[r][cI] = 0.0;
+      I[cI][cI] = ir[cI];
+#pragma unroll
+      for (int r = cI + 1; r < 6; ++r) { double s = 0.0;
+#pragma unroll
+        for (int k = cI; k < r; ++k) s -= L[r][k] * I[k][cI];
+        I[r][cI] = s * ir[r]; }
+    }
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+      for (int b = 0; b < 6; ++b) { Li[a * 6 + b] = (b <= a) ? I[a][b] : 0.0; }
+    for (int k = 0; k < 36; ++k) d.Linv[(size_t)jf * 36 + k] = Li[k];
+  };
+#ifdef LIFCAL_STAMPS
+  unsigned long long cst[6] = {0, 0, 0, 0, 0, 0}, clast = 0;
+  if (lane == 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(clast) :: "memory");
+#define CSTAMP(i) do { if (lane == 0) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); cst[i] += t_ - clast; clast = t_; } } while (0)
+#else
+#define CSTAMP(i) do { } while (0)
+#endif
+  // ---- the chain over the pose blocks ----
+  for (uint32_t j = 0; j < F; ++j) {
+    const uint32_t sj = slot(j);
+    CSTAMP(5);
+    if (j == 0 && lane == 192) factor_block(0, false);   // later blocks are factored by wave 3 inside the previous step's update
+    CSTAMP(0);
     __syncthreads();
+    CSTAMP(1);
     const uint32_t nbel = min(bw, F - 1 - j);
     const uint32_t nrows = 6 * nbel + NAx;
     double* Lp = Lpanel + (size_t)j * (6 * bw + NAx) * 6;
@@ -114,8 +145,9 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
         for (int k = 0; k <= cI; ++k) s += x[k] * Li[cI * 6 + k];
         y[cI] = s; }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) { Pn[(size_t)r * 6 + k] = y[k]; Lp[(size_t)r * 6 + k] = y[k]; }
+      for (int k = 0; k < 6; ++k) { Pn[(size_t)k * NR + r] = y[k]; Lp[(size_t)r * 6 + k] = y[k]; }
     }
+    CSTAMP(2);
     __syncthreads();
     // the frame that enters the ring after this step: issue its HBM loads now, commit them to LDS after the update
     // (up to 2 band values + 1 arrow value per thread for bw <= 13; wider bands take the plain path below)
@@ -128,19 +160,60 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
       for (int q = 0; q < 2; ++q) { const uint32_t t = lane + 256 * q; if (t < R * 36) pfv[q] = d.Sband[((size_t)f * (bw + 1) + t / 36) * 36 + t % 36]; }
       if (lane < NAx * 6) pfv[2] = d.Sarrow[(size_t)(lane / 6) * ld + 6 * f + lane % 6];
     }
-    // rank-6 update of the window: thread = (row r = tid mod 64 [+64..], column phase tid / 64), columns c <= r step 4
-    // (a 4x4-blocked mapping with one block per thread was measured: slower, the step is bound by its barriers and the
-    // single-lane diagonal factor, not by this update)
-    for (uint32_t r = lane & 63u; r < nrows; r += 64) {
-      const uint32_t wr = wmap[r];
-      const double* pr = Pn + (size_t)r * 6;
-      const double p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3], p4 = pr[4], p5 = pr[5];
-      for (uint32_t cI = lane >> 6; cI <= r; cI += 4) {
-        const double* pc = Pn + (size_t)cI * 6;
-        Wd[(size_t)wr * nw + wmap[cI]] -= p0 * pc[0] + p1 * pc[1] + p2 * pc[2] + p3 * pc[3] + p4 * pc[4] + p5 * pc[5];
+    // rank-6 update of the window in 4x4 blocks of (panel row, panel row) pairs over the lower triangle, one block per
+    // thread.  The phase is bound by LDS traffic: the panel is stored component-major (Pn[k][row]) so that the four rows of
+    // a block are one 32-byte run per component (12 + 12 ds_read_b128 for 96 MACs, no bank-conflicting 48-byte strides),
+    // 5.5 LDS operations per pair instead of 9 with a row per thread, and every thread has the same amount of work.
+    // The diagonal block of frame j+1 receives its last contribution from this column: lane 192 (wave 3, idle in the
+    // blocked update below for the usual band widths) applies it first and factors the block right away, so that the
+    // single-lane factorisation of step j+1 runs UNDER this step's update instead of in front of the next one.
+    const bool ahead = nbel > 0;
+    if (ahead && lane == 192) factor_block(j + 1, true);   // (the block itself is not written back: nothing reads it after its factorisation)
+    {
+      const uint32_t nb4 = (nrows + 3u) >> 2, nblk = nb4 * (nb4 + 1) / 2;
+      const uint32_t first = lane < 192 ? lane : lane - 192 + 192;   // (all four waves take blocks; lane 192 joins after its factorisation)
+      for (uint32_t t = first; t < nblk; t += 256) {
+        uint32_t bi = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while (bi * (bi + 1) / 2 > t) --bi;
+        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+        const uint32_t bj = t - bi * (bi + 1) / 2;
+        double2 pr[6][2], pc[6][2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          pr[k][0] = *reinterpret_cast<const double2*>(Pn + (size_t)k * NR + 4 * bi); pr[k][1] = *reinterpret_cast<const double2*>(Pn + (size_t)k * NR + 4 * bi + 2);
+          pc[k][0] = *reinterpret_cast<const double2*>(Pn + (size_t)k * NR + 4 * bj); pc[k][1] = *reinterpret_cast<const double2*>(Pn + (size_t)k * NR + 4 * bj + 2);
+        }
+        uint32_t wr[4], wc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { wr[i] = wmap[min(4 * bi + i, nrows - 1)] * nw; wc[i] = wmap[min(4 * bj + i, nrows - 1)]; }
+        // the 16 window entries are read first and written last: one by one the compiler has to assume that they alias
+        // and pays an LDS round trip per entry
+        double oldv[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) oldv[i][jx] = Wd[wr[i] + wc[jx]];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) {
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) sacc += ((i & 1) ? pr[k][i >> 1].y : pr[k][i >> 1].x) * ((jx & 1) ? pc[k][jx >> 1].y : pc[k][jx >> 1].x);
+            oldv[i][jx] -= sacc;
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) {
+            const uint32_t r = 4 * bi + i, cI = 4 * bj + jx;
+            if (r < nrows && cI <= r && !(ahead && r < 6)) Wd[wr[i] + wc[jx]] = oldv[i][jx];
+          }
       }
     }
+    CSTAMP(3);
     __syncthreads();
+    CSTAMP(4);
     // slide: frame j leaves its slot, frame j + bw + 1 (if any) enters it.  No zeroing is needed: every entry of the
     // slot's row that is read later is overwritten here (all bw+1 blocks of the incoming frame), and stale entries of
     // the slot's column are overwritten when the rows that use them enter.
@@ -159,6 +232,9 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
       __syncthreads();
     }
   }
+#ifdef LIFCAL_STAMPS
+  if (lane == 0 && d.dbg) for (int i = 0; i < 6; ++i) d.dbg[i] = cst[i];
+#endif
   // ---- dense Cholesky of the arrow block (NA x NA), rhs row carried along ----
   double* Aa = Wd + (size_t)arow0 * nw + arow0;   // Aa[a * nw + b]
   for (uint32_t cI = 0; cI < d.NA; ++cI) {
@@ -205,7 +281,7 @@ __global__ __launch_bounds__(64) void k_band_backsolve_w(Dev d, const double* Lp
   // is requested before the current column is reduced, the reduction runs on DPP (no LDS crossbar shuffles), and the
   // rhs row is read where it is needed instead of being summed over the wave.
   const uint32_t prow = 6 * bw + NAx;   // panel rows reserved per column
-  double nx[2][6], ny = 0.0;
+  double nx[2][6], ny = 0.0, nli[6];   // nli: column `lane` of L_jj^-1 (lanes 0-5), fetched with the panel
   auto fetch = [&](int jj) {
     const uint32_t nb = min(bw, F - 1 - (uint32_t)jj), nr = 6 * nb + NAx;
     const double* Lp = Lpanel + (size_t)jj * prow * 6;
@@ -217,6 +293,8 @@ __global__ __launch_bounds__(64) void k_band_backsolve_w(Dev d, const double* Lp
       for (int k = 0; k < 6; ++k) nx[q][k] = row[k];
     }
     ny = Lp[(size_t)(nr - 1) * 6 + (lane < 6 ? lane : 0)];          // y_j: the rhs row of the panel (forward substitution done by the factorisation)
+#pragma unroll
+    for (int k = 0; k < 6; ++k) nli[k] = d.Linv[(size_t)jj * 36 + k * 6 + (lane < 6 ? lane : 0)];
   };
   if (F > 0) fetch((int)F - 1);
   for (int j = (int)F - 1; j >= 0; --j) {
@@ -229,6 +307,9 @@ __global__ __launch_bounds__(64) void k_band_backsolve_w(Dev d, const double* Lp
 #pragma unroll
       for (int k = 0; k < 6; ++k) cur[q][k] = nx[q][k];
     const double yj = ny;
+    double li[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) li[k] = nli[k];
     if (j > 0) fetch(j - 1);
     double acc[6] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -257,12 +338,11 @@ __global__ __launch_bounds__(64) void k_band_backsolve_w(Dev d, const double* Lp
 #pragma unroll
     for (int k = 0; k < 6; ++k) if (lane == (uint32_t)k) tk = yj - tot[k];
     if (lane < 6) {
-      const double* Li = d.Linv + (size_t)j * 36;
       double o = 0.0;
 #pragma unroll
       for (int k = 0; k < 6; ++k) {
         const double t = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(tk), k), __builtin_amdgcn_readlane(__double2loint(tk), k));
-        if (k >= (int)lane) o += Li[k * 6 + lane] * t;
+        if (k >= (int)lane) o += li[k] * t;
       }
       xs[6 * j + lane] = o;
     }
