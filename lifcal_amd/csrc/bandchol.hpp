@@ -16,11 +16,11 @@
 namespace lifcal {
 
 struct BandLds {
-  uint32_t nw, nr4, off_pn, off_d, off_map, total;   // window | panel, component-major (6 x nr4) | L_jj, L_jj^-1, flag | window row of each panel row
+  uint32_t nw, nr4, off_pn, off_d, off_map, off_dummy, total;   // window | panel, component-major (6 x nr4) | L_jj, L_jj^-1, flag | window row of each panel row
   __host__ __device__ BandLds(uint32_t bw, uint32_t NA) {
     nw = 6 * (bw + 1) + NA + 1;
     nr4 = (nw + 3u) & ~3u;
-    off_pn = (nw * nw + 1u) & ~1u; off_d = off_pn + nr4 * 6; off_map = off_d + 80; total = off_map + (nr4 + 1) / 2 + 1;
+    off_pn = (nw * nw + 1u) & ~1u; off_d = off_pn + nr4 * 6; off_map = off_d + 80; off_dummy = off_map + (nr4 + 1) / 2 + 1; total = off_dummy + 256;   // ... | one scratch double per thread
   }
 };
 
@@ -121,13 +121,23 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
 #else
 #define CSTAMP(i) do { } while (0)
 #endif
+  auto tri_block = [](uint32_t t, uint32_t& bi, uint32_t& bj) {
+    bi = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while (bi * (bi + 1) / 2 > t) --bi;
+    while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+    bj = t - bi * (bi + 1) / 2;
+  };
+  uint32_t bi0, bj0;
+  tri_block(lane, bi0, bj0);
   // ---- the chain over the pose blocks ----
+  // (barriers inside the chain order LDS only: __syncthreads() would also wait for the panel / L^-1 stores on their way to
+  // HBM — a write round trip per barrier, four per pose block — and nothing in the chain reads them back)
   for (uint32_t j = 0; j < F; ++j) {
     const uint32_t sj = slot(j);
     CSTAMP(5);
     if (j == 0 && lane == 192) factor_block(0, false);   // later blocks are factored by wave 3 inside the previous step's update
     CSTAMP(0);
-    __syncthreads();
+    lds_barrier();
     CSTAMP(1);
     const uint32_t nbel = min(bw, F - 1 - j);
     const uint32_t nrows = 6 * nbel + NAx;
@@ -148,7 +158,7 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
       for (int k = 0; k < 6; ++k) { Pn[(size_t)k * NR + r] = y[k]; Lp[(size_t)r * 6 + k] = y[k]; }
     }
     CSTAMP(2);
-    __syncthreads();
+    lds_barrier();
     // the frame that enters the ring after this step: issue its HBM loads now, commit them to LDS after the update
     // (up to 2 band values + 1 arrow value per thread for bw <= 13; wider bands take the plain path below)
     const bool has_next = (j + R < F);
@@ -173,10 +183,8 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
       const uint32_t nb4 = (nrows + 3u) >> 2, nblk = nb4 * (nb4 + 1) / 2;
       const uint32_t first = lane < 192 ? lane : lane - 192 + 192;   // (all four waves take blocks; lane 192 joins after its factorisation)
       for (uint32_t t = first; t < nblk; t += 256) {
-        uint32_t bi = (uint32_t)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-        while (bi * (bi + 1) / 2 > t) --bi;
-        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-        const uint32_t bj = t - bi * (bi + 1) / 2;
+        uint32_t bi = bi0, bj = bj0;   // block of t = lane, decoded once before the chain (a shorter panel uses a prefix of the blocks)
+        if (t != lane) tri_block(t, bi, bj);
         double2 pr[6][2], pc[6][2];
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
@@ -186,13 +194,23 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
         uint32_t wr[4], wc[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) { wr[i] = wmap[min(4 * bi + i, nrows - 1)] * nw; wc[i] = wmap[min(4 * bj + i, nrows - 1)]; }
-        // the 16 window entries are read first and written last: one by one the compiler has to assume that they alias
-        // and pays an LDS round trip per entry
+        // branch-free: entries that are not this block's to update (upper triangle of a diagonal block, rows past the panel,
+        // the six rows lane 192 takes) are pointed at the thread's scratch double; all reads come before all writes (written
+        // one by one the compiler has to assume that the entries alias and pays an LDS round trip per entry)
+        const uint32_t scratch = lay.off_dummy + lane;
+        uint32_t wa[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int jx = 0; jx < 4; ++jx) {
+            const uint32_t r = 4 * bi + i, cI = 4 * bj + jx;
+            wa[i][jx] = (r < nrows && cI <= r && !(ahead && r < 6)) ? wr[i] + wc[jx] : scratch;
+          }
         double oldv[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int jx = 0; jx < 4; ++jx) oldv[i][jx] = Wd[wr[i] + wc[jx]];
+          for (int jx = 0; jx < 4; ++jx) oldv[i][jx] = bl[wa[i][jx]];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -200,23 +218,15 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
             double sacc = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) sacc += ((i & 1) ? pr[k][i >> 1].y : pr[k][i >> 1].x) * ((jx & 1) ? pc[k][jx >> 1].y : pc[k][jx >> 1].x);
-            oldv[i][jx] -= sacc;
-          }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int jx = 0; jx < 4; ++jx) {
-            const uint32_t r = 4 * bi + i, cI = 4 * bj + jx;
-            if (r < nrows && cI <= r && !(ahead && r < 6)) Wd[wr[i] + wc[jx]] = oldv[i][jx];
+            bl[wa[i][jx]] = oldv[i][jx] - sacc;
           }
       }
     }
-    CSTAMP(3);
-    __syncthreads();
-    CSTAMP(4);
-    // slide: frame j leaves its slot, frame j + bw + 1 (if any) enters it.  No zeroing is needed: every entry of the
-    // slot's row that is read later is overwritten here (all bw+1 blocks of the incoming frame), and stale entries of
-    // the slot's column are overwritten when the rows that use them enter.
+    // slide: frame j leaves its slot, frame j + bw + 1 (if any) enters it — in the SAME phase as the update: the update
+    // touches rows and columns of the frames j+1..j+bw and of the arrow only, the incoming frame's row and column live in
+    // the slot frame j has just vacated (its column was last read by the panel phase, a barrier ago).  No zeroing is
+    // needed: every entry of the slot's row that is read later is overwritten here (all bw+1 blocks of the incoming frame),
+    // and stale entries of the slot's column are overwritten when the rows that use them enter.
     if (has_next) {
       const uint32_t f = j + R;
       if (pf) {
@@ -229,8 +239,10 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
       } else {
         load_frame_row(f);
       }
-      __syncthreads();
     }
+    CSTAMP(3);
+    lds_barrier();
+    CSTAMP(4);
   }
 #ifdef LIFCAL_STAMPS
   if (lane == 0 && d.dbg) for (int i = 0; i < 6; ++i) d.dbg[i] = cst[i];
