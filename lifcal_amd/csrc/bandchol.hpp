@@ -358,7 +358,7 @@ __global__ __launch_bounds__(64) void k_band_backsolve_w(Dev d, const double* Lp
       }
       xs[6 * j + lane] = o;
     }
-    __syncthreads();
+    lds_barrier();   // LDS ordering only (a two-steps-ahead prefetch was measured: no gain, the step is instruction-bound on one wave)
   }
   for (uint32_t k = lane; k < d.n_red; k += 64) d.delta_red[k] = xs[k];
 }
