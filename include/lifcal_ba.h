@@ -239,6 +239,32 @@ int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size,
                    uint32_t* obs_order /* [n_obs] or NULL: sorted position -> input index, UINT32_MAX-padded */,
                    uint32_t* point_owner /* [n_points] or NULL: rank owning each point */);
 
+/* ---- start values of the plenoptic parameters ----
+ * Replaces reference src/CameraCalibration.cpp:456-499 (CameraCalibration::initPlenopticParameters): with
+ * bL = fL z / (z - fL), z the camera-frame depth of the object point of an image point, the linear model
+ * bL = v B + bL0 (v = virtual depth) is fitted over all image points of all frames in the least-squares sense; a row is
+ * dropped (zeroed, as the reference does) when v < 2 or bL < 0.  The reference solves with Eigen::JacobiSVD, i.e. the
+ * minimum-norm solution with singular values below 2 eps sigma_max treated as zero; so does this.
+ * Inputs are plain host arrays, one entry per image point in the reference's frame-major order (any order works).  The
+ * sums run on the device (one reduction kernel), the 2x2 solve on the host. */
+typedef struct lifcal_init_problem {
+  uint64_t n;                 /* image points over all frames (reference: sum of frames[i].imageCoordinates.size())      */
+  const double* vdepth;       /* [n] virtual depth of the point (reference virtualDepthValues[i][p])                      */
+  const uint32_t* fr;         /* [n] frame of the point                                                                    */
+  const uint32_t* pt;         /* [n] index of its object point (reference objectCoordinatesByID[p] - p3d_w.data())        */
+  uint32_t n_frames, n_points;
+  const double* world_to_cam; /* [n_frames][16] COLUMN-major, as Eigen::Matrix4d frame::worldToCam stores it              */
+  const double* pts;          /* [n_points][3]                                                                             */
+  double fL_init;             /* fPH_init * pixelSize_totFoc (reference :460)                                              */
+} lifcal_init_problem;
+typedef struct lifcal_init_result {
+  double B_init, bL0_init;    /* x[0], x[1] of the reference (:492-493)                                                    */
+  uint64_t n_used;            /* rows that entered the fit                                                                 */
+  int32_t rank;               /* numerical rank of the n x 2 system (2 unless degenerate)                                  */
+  int32_t reserved;
+} lifcal_init_result;
+int lifcal_init_plenoptic(const lifcal_init_problem* p, int32_t device, lifcal_init_result* out);
+
 #ifdef __cplusplus
 }
 #endif

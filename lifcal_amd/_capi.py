@@ -82,6 +82,32 @@ class PlanInfo(C.Structure):
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 
+class InitProblem(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("vdepth", C.POINTER(C.c_double)), ("fr", C.POINTER(C.c_uint32)), ("pt", C.POINTER(C.c_uint32)),
+                ("n_frames", C.c_uint32), ("n_points", C.c_uint32), ("world_to_cam", C.POINTER(C.c_double)), ("pts", C.POINTER(C.c_double)),
+                ("fL_init", C.c_double)]
+
+
+class InitResult(C.Structure):
+    _fields_ = [("B_init", C.c_double), ("bL0_init", C.c_double), ("n_used", C.c_uint64), ("rank", C.c_int32), ("reserved", C.c_int32)]
+
+
+class InitArrays:
+    """Owns contiguous copies of the inputs of lifcal_init_plenoptic / lo_init_plenoptic."""
+
+    def __init__(self, vdepth, fr, pt, world_to_cam, pts, fL_init):
+        self.vdepth = np.ascontiguousarray(vdepth, np.float64)
+        self.fr = np.ascontiguousarray(fr, np.uint32)
+        self.pt = np.ascontiguousarray(pt, np.uint32)
+        # (F, 4, 4) matrices in mathematical (row, column) indexing -> Eigen's column-major storage
+        w = np.asarray(world_to_cam, np.float64).reshape(-1, 4, 4)
+        self.w2c = np.ascontiguousarray(np.transpose(w, (0, 2, 1)).reshape(-1, 16))
+        self.pts = np.ascontiguousarray(np.asarray(pts, np.float64).reshape(-1, 3))
+        assert len(self.vdepth) == len(self.fr) == len(self.pt)
+        self.struct = InitProblem(len(self.vdepth), as_dptr(self.vdepth), as_uptr(self.fr), as_uptr(self.pt), len(self.w2c), len(self.pts),
+                                  as_dptr(self.w2c), as_dptr(self.pts), float(fL_init))
+
+
 # every symbol include/lifcal_ba.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     "lifcal_ba_default_options": (None, [C.POINTER(Options)]),
@@ -100,6 +126,7 @@ PROTOTYPES = {
     "lifcal_ba_comm_init_rccl": (C.c_int, [C.c_void_p, C.c_void_p]),
     "lifcal_ba_get_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
     "lifcal_ba_destroy": (None, [C.c_void_p]),
+    "lifcal_init_plenoptic": (C.c_int, [C.POINTER(InitProblem), C.c_int32, C.POINTER(InitResult)]),
     "lifcal_ba_strerror": (C.c_char_p, [C.c_int]),
     "lifcal_ba_last_error": (C.c_char_p, []),
     "lifcal_ba_version": (C.c_char_p, []),

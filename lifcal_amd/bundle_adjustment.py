@@ -168,6 +168,17 @@ def comm_unique_id() -> bytes:
     return buf.raw
 
 
+def initPlenopticParameters(vdepth, fr, pt, world_to_cam, pts, fL_init, device: int = 0):
+    """Start values (B_init, bL0_init) of the plenoptic parameters — reference CameraCalibration::initPlenopticParameters
+    (src/CameraCalibration.cpp:456-499).  vdepth / fr / pt: one entry per image point (virtual depth, frame, object point);
+    world_to_cam: (F, 4, 4) matrices; pts: (P, 3); fL_init = fPH_init * pixelSize_totFoc.  Returns capi.InitResult."""
+    lib = capi.load_library()
+    arrs = capi.InitArrays(vdepth, fr, pt, world_to_cam, pts, fL_init)
+    res = capi.InitResult()
+    _check(lib, lib.lifcal_init_plenoptic(C.byref(arrs.struct), int(device), C.byref(res)), "lifcal_init_plenoptic")
+    return res
+
+
 def plan(problem: capi.ProblemArrays, rank: int = 0, world_size: int = 1):
     """Host-only layout planning (no GPU needed): returns (PlanInfo, obs_order, point_owner)."""
     lib = capi.load_library()

@@ -547,6 +547,29 @@ __global__ __launch_bounds__(256) void k_schur(Dev d, double radius) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// start values of the plenoptic parameters (reference src/CameraCalibration.cpp:456-499): the five sums of the
+// normal equations of bL = v B + bL0 over the valid rows, and the number of rows with an index out of range
+// out: [0] sum v^2  [1] sum v  [2] rows used  [3] sum v bL  [4] sum bL  [5] bad indices
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_init_sums(uint64_t n, const double* vdepth, const uint32_t* fr, const uint32_t* pt, uint32_t n_frames,
+                                                   uint32_t n_points, const double* w2c, const double* pts, double fL, double* out) {
+  double s[6] = {0, 0, 0, 0, 0, 0};
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint32_t f = fr[i], q = pt[i];
+    if (f >= n_frames || q >= n_points) { s[5] += 1.0; continue; }
+    const double* M = w2c + (size_t)f * 16;   // column-major 4x4: row 2 is the camera-frame z
+    const double* P = pts + 3 * (size_t)q;
+    const double z = M[2] * P[0] + M[6] * P[1] + M[10] * P[2] + M[14];
+    const double bL = (fL * z) / (z - fL);     // reference :483
+    const double v = vdepth[i];
+    if ((v < 2.0) || (bL < 0.0)) continue;     // reference :485-490 zeroes the row (NaN compares false: the row stays, as there)
+    s[0] += v * v; s[1] += v; s[2] += 1.0; s[3] += v * bL; s[4] += bL;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) { s[k] = wave_sum(s[k]); if ((threadIdx.x & 63u) == 0 && s[k] != 0.0) atomicAdd(out + k, s[k]); }
+}
+
+// ---------------------------------------------------------------------------------------------
 // multi-GPU exchange of the reduced block as frame slabs (see lifcal_ba_allgather_fn in include/lifcal_ba.h)
 // slab of one rank: band [maxn][BS] | camera x pose [maxn][NA][6] | rhsacc,gB,hdiag [maxn][3][6] |
 //                   tail: arrow x arrow [NA][NA] | camera entries of the three vectors [3][NA] | scal[SCAL_N]

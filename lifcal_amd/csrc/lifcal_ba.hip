@@ -436,6 +436,60 @@ const char* lifcal_ba_strerror(int code) {
 const char* lifcal_ba_last_error(void) { return g_last_error.c_str(); }
 const char* lifcal_ba_version(void) { return "lifcal_amd 0.1 (gfx950)"; }
 
+// min-norm least squares for the n x 2 system through the eigen-decomposition of its 2 x 2 Gram matrix: what
+// Eigen::JacobiSVD::solve returns (singular values <= 2 eps sigma_max count as zero), reference CameraCalibration.cpp:491
+static void solve_n_by_2(double a, double b, double c, double r0, double r1, double* x0, double* x1, int* rank) {
+  // G = [a b; b c] = A^T A, r = A^T rhs
+  const double tr = a + c, df = a - c, rad = std::sqrt(df * df + 4.0 * b * b);
+  double l1 = 0.5 * (tr + rad), l2 = 0.5 * (tr - rad);
+  if (l2 < 0.0) l2 = 0.0;
+  double v1x, v1y;   // unit eigenvector of l1
+  if (std::fabs(b) > 0.0) { v1x = l1 - c; v1y = b; } else if (a >= c) { v1x = 1.0; v1y = 0.0; } else { v1x = 0.0; v1y = 1.0; }
+  const double nv = std::sqrt(v1x * v1x + v1y * v1y);
+  if (nv > 0.0) { v1x /= nv; v1y /= nv; } else { v1x = 1.0; v1y = 0.0; }
+  const double v2x = -v1y, v2y = v1x;
+  const double smax = std::sqrt(l1), thr = 2.0 * 2.220446049250313e-16 * smax;
+  *rank = 0; *x0 = 0.0; *x1 = 0.0;
+  if (l1 > 0.0 && std::sqrt(l1) > thr) { const double t = (v1x * r0 + v1y * r1) / l1; *x0 += t * v1x; *x1 += t * v1y; ++*rank; }
+  if (l2 > 0.0 && std::sqrt(l2) > thr) { const double t = (v2x * r0 + v2y * r1) / l2; *x0 += t * v2x; *x1 += t * v2y; ++*rank; }
+}
+
+int lifcal_init_plenoptic(const lifcal_init_problem* p, int32_t device, lifcal_init_result* out) {
+  if (!p || !out || (p->n && (!p->vdepth || !p->fr || !p->pt)) || (p->n_frames && !p->world_to_cam) || (p->n_points && !p->pts)) {
+    g_last_error = "lifcal_init_plenoptic: null argument"; return LIFCAL_BA_ERR_INVALID_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) { g_last_error = "no HIP device (this path has no CPU fallback)"; return LIFCAL_BA_ERR_NO_DEVICE; }
+  HIP_TRY(hipSetDevice(device));
+  double *dv = nullptr, *dw = nullptr, *dp = nullptr, *dout = nullptr; uint32_t *df = nullptr, *dq = nullptr;
+  auto release = [&]() { for (void* q : {(void*)dv, (void*)dw, (void*)dp, (void*)dout, (void*)df, (void*)dq}) if (q) (void)hipFree(q); };
+  auto up = [&](void** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(dst, bytes ? bytes : 8); if (e != hipSuccess) return e;
+    return bytes ? hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) : hipSuccess;
+  };
+  hipError_t e = up((void**)&dv, p->vdepth, p->n * 8);
+  if (e == hipSuccess) e = up((void**)&df, p->fr, p->n * 4);
+  if (e == hipSuccess) e = up((void**)&dq, p->pt, p->n * 4);
+  if (e == hipSuccess) e = up((void**)&dw, p->world_to_cam, (size_t)p->n_frames * 16 * 8);
+  if (e == hipSuccess) e = up((void**)&dp, p->pts, (size_t)p->n_points * 3 * 8);
+  if (e == hipSuccess) e = hipMalloc((void**)&dout, 6 * 8);
+  if (e == hipSuccess) e = hipMemset(dout, 0, 6 * 8);
+  double h[6] = {0, 0, 0, 0, 0, 0};
+  if (e == hipSuccess) {
+    const unsigned grid = (unsigned)std::min<uint64_t>(std::max<uint64_t>((p->n + 255) / 256, 1), 4096);
+    hipLaunchKernelGGL(k_init_sums, dim3(grid), dim3(256), 0, 0, p->n, dv, df, dq, p->n_frames, p->n_points, dw, dp, p->fL_init, dout);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpy(h, dout, sizeof(h), hipMemcpyDeviceToHost);
+  }
+  release();
+  if (e != hipSuccess) { g_last_error = std::string("lifcal_init_plenoptic: ") + hipGetErrorString(e); return LIFCAL_BA_ERR_HIP; }
+  if (h[5] != 0.0) { g_last_error = "lifcal_init_plenoptic: frame or point index out of range"; return LIFCAL_BA_ERR_OUT_OF_RANGE; }
+  int rank = 0;
+  solve_n_by_2(h[0], h[1], h[2], h[3], h[4], &out->B_init, &out->bL0_init, &rank);
+  out->n_used = (uint64_t)h[2]; out->rank = rank; out->reserved = 0;
+  return 0;
+}
+
 int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size, lifcal_ba_plan_info* info,
                    uint32_t* obs_order, uint32_t* point_owner) {
   Plan pl;

@@ -54,6 +54,17 @@ def _dp(a):
     return a.ctypes.data_as(capi.dptr) if a is not None else None
 
 
+def init_plenoptic(arrs: capi.InitArrays) -> capi.InitResult:
+    """reference CameraCalibration::initPlenopticParameters (src/CameraCalibration.cpp:456-499) on the CPU"""
+    res = capi.InitResult()
+    L = lib()
+    L.lo_init_plenoptic.restype = C.c_int
+    L.lo_init_plenoptic.argtypes = [C.POINTER(capi.InitProblem), C.POINTER(capi.InitResult)]
+    rc = L.lo_init_plenoptic(C.byref(arrs.struct), C.byref(res))
+    assert rc == 0, rc
+    return res
+
+
 def hardware_threads() -> int:
     return int(lib().lo_hardware_threads())
 

@@ -966,4 +966,54 @@ int lo_reproj_stats(const lifcal_ba_problem* p, double thr, lifcal_ba_stats* out
 
 int lo_hardware_threads(void) { return (int)std::thread::hardware_concurrency(); }
 
+// ------------------------------------------------------------------------------------------------
+// reference src/CameraCalibration.cpp:456-499, CameraCalibration::initPlenopticParameters.
+//   :469-471  a = ones(n, 2), b(n)                    :479 a(row,0) = virtual depth
+//   :481-483  p_c = worldToCam * P.homogeneous();  b = fL z / (z - fL)
+//   :485-490  rows with v < 2 or b < 0 are zeroed     :491 x = a.jacobiSvd(ThinU | ThinV).solve(b)
+// Eigen (out of tree) computes the SVD of the n x 2 matrix with two-sided Jacobi sweeps after a QR step; for two columns
+// that is one Givens rotation of the column pair, restated here as a one-sided (Hestenes) Jacobi SVD: rotate the two
+// columns until they are orthogonal, singular values = column norms, x = V S^+ U^T b with S^+ dropping singular values
+// <= 2 eps sigma_max (Eigen's default threshold: diagSize * epsilon).
+// ------------------------------------------------------------------------------------------------
+int lo_init_plenoptic(const lifcal_init_problem* p, lifcal_init_result* out) {
+  if (!p || !out) return -1;
+  const uint64_t n = p->n;
+  std::vector<double> c0(n), c1(n), rhs(n);
+  uint64_t used = 0;
+  for (uint64_t i = 0; i < n; ++i) {
+    if (p->fr[i] >= p->n_frames || p->pt[i] >= p->n_points) return -4;
+    const double* M = p->world_to_cam + (size_t)p->fr[i] * 16;   // column-major Matrix4d
+    const double* P = p->pts + 3 * (size_t)p->pt[i];
+    double pc[4];
+    for (int r = 0; r < 4; ++r) pc[r] = M[r] * P[0] + M[4 + r] * P[1] + M[8 + r] * P[2] + M[12 + r] * 1.0;
+    const double z = pc[2];
+    double a0 = p->vdepth[i], a1 = 1.0, b = (p->fL_init * z) / (z - p->fL_init);
+    if ((p->vdepth[i] < 2) || (b < 0)) { a0 = 0; a1 = 0; b = 0; } else ++used;
+    c0[i] = a0; c1[i] = a1; rhs[i] = b;
+  }
+  // one-sided Jacobi on the column pair; V accumulates the rotations
+  double V[2][2] = {{1, 0}, {0, 1}};
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    long double al = 0, be = 0, ga = 0;
+    for (uint64_t i = 0; i < n; ++i) { al += (long double)c0[i] * c0[i]; be += (long double)c1[i] * c1[i]; ga += (long double)c0[i] * c1[i]; }
+    if (std::fabs((double)ga) <= 1e-300 || std::fabs((double)ga) <= 2.220446049250313e-16 * std::sqrt((double)al * (double)be)) break;
+    const double zeta = (double)((be - al) / (2.0L * ga));
+    const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+    const double cs = 1.0 / std::sqrt(1.0 + t * t), sn = cs * t;
+    for (uint64_t i = 0; i < n; ++i) { const double x0 = c0[i], x1 = c1[i]; c0[i] = cs * x0 - sn * x1; c1[i] = sn * x0 + cs * x1; }
+    for (int r = 0; r < 2; ++r) { const double v0 = V[r][0], v1 = V[r][1]; V[r][0] = cs * v0 - sn * v1; V[r][1] = sn * v0 + cs * v1; }
+  }
+  long double s0 = 0, s1 = 0, u0b = 0, u1b = 0;
+  for (uint64_t i = 0; i < n; ++i) { s0 += (long double)c0[i] * c0[i]; s1 += (long double)c1[i] * c1[i]; u0b += (long double)c0[i] * rhs[i]; u1b += (long double)c1[i] * rhs[i]; }
+  const double sg0 = std::sqrt((double)s0), sg1 = std::sqrt((double)s1), smax = std::max(sg0, sg1), thr = 2.0 * 2.220446049250313e-16 * smax;
+  double x[2] = {0, 0}; int rank = 0;
+  // U_k = c_k / sigma_k, so V S^+ U^T b = sum_k V[:,k] (c_k . b) / sigma_k^2
+  if (sg0 > thr && sg0 > 0) { const double w = (double)u0b / (double)s0; x[0] += V[0][0] * w; x[1] += V[1][0] * w; ++rank; }
+  if (sg1 > thr && sg1 > 0) { const double w = (double)u1b / (double)s1; x[0] += V[0][1] * w; x[1] += V[1][1] * w; ++rank; }
+  out->B_init = x[0]; out->bL0_init = x[1]; out->n_used = used; out->rank = rank; out->reserved = 0;
+  return 0;
+}
+
+
 }  // extern "C"

@@ -23,6 +23,8 @@ int lo_sweep(const lifcal_ba_problem* p, const lifcal_ba_options* o, double radi
 int lo_solve(const lifcal_ba_problem* p, const lifcal_ba_options* o, int threads, lifcal_ba_summary* sum);
 int lo_reproj_stats(const lifcal_ba_problem* p, double thr, lifcal_ba_stats* out, double* errors_2n);
 int lo_hardware_threads(void);
+/* reference src/CameraCalibration.cpp:456-499 (initPlenopticParameters), JacobiSVD restated as a one-sided Jacobi SVD */
+int lo_init_plenoptic(const lifcal_init_problem* p, lifcal_init_result* out);
 #ifdef __cplusplus
 }
 #endif
