@@ -1,4 +1,5 @@
-"""Diagnostic: per-phase cycle shares of k_sweep2 from the LIFCAL_STAMPS build (never used for timing claims)."""
+"""Diagnostic: per-phase cycle shares of the LDS-window sweep kernel from the LIFCAL_STAMPS build (never used for timing
+claims): thread 0 (evaluator wave 0) and, for k_sweep3, thread 256 (accumulator wave 0, rows "acc: ...")."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -18,7 +19,7 @@ n = lib.lifcal_ba_debug_stamps(ba._h, buf.ctypes.data, info.n_chunks)
 st = buf.reshape(-1, 32)[:n].astype(np.float64)
 names = ["zero+sync", "phase1 wait@sync", "phase2 factor", "phase3 W->HBM,Z", "phase4 schur", "flush to HBM", "phase1 emission(w0)", "phase1 obs loop(w0)",
          "(slack)", "tile emit", "cc/gc/cost reduce", "replica fold", "pass top (prefetch issue)", "zero stores", "prologue", "",
-         "B: pass top", "B: obs loop", "B: P2a+zero+P2", "B: emission", "B: wait P3", "B: factor..schur (idle/Z)", "", "", "", "", "", "", "", "", "", ""]
+         "acc: pass top", "acc: obs loop", "acc: P2a+zero+P2", "acc: emission", "acc: wait P4", "acc: Z + Schur half", "", "", "", "", "", "", "", "", "", ""]
 tot = st[:, :16].sum(1)
 print(f"{name}: blocks {n}, sweep {r.seconds*1e6:.1f} us; cycles per block: mean {tot.mean():.0f} max {tot.max():.0f} min {tot.min():.0f}")
 for i, nm in enumerate(names):
