@@ -24,8 +24,13 @@ def _worker(rank, world, port, out_dir, spec_kw, mode):
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     hip.hipStreamSynchronize.argtypes = [C.c_void_p]
-    sc = scene.make_scene(scene.SceneSpec(**spec_kw))
-    pa = capi.ProblemArrays.from_scene(sc)
+    if "stress_case" in spec_kw:          # a deformed scene of tests/test_gpu_stress.py
+        from tests.test_gpu_stress import deformed_problem
+        _, mk, _ = deformed_problem(spec_kw["stress_case"])
+        pa = mk()
+    else:
+        sc = scene.make_scene(scene.SceneSpec(**spec_kw))
+        pa = capi.ProblemArrays.from_scene(sc)
     o = capi.default_options_py(); o.rank = rank; o.world_size = world
     ba = BundleAdjustment(pa, o)
 
@@ -103,3 +108,25 @@ def test_ranks_match_the_single_process_oracle(built, tmp_path, spec_kw, mode, w
     assert np.array_equal(r0["pts"], r1["pts"]) and np.array_equal(r0["cam"], r1["cam"])
     stt = oracle.reproj_stats(capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, r0["cam"], r0["views"], r0["pts"], sc.spx, sc.scale, sc.config))
     assert abs(float(r0["stats"][0]) - stt.std_x) < 1e-9 and int(r0["stats"][2]) == sc.n_obs
+
+
+@pytest.mark.parametrize("k,world", [(10, 2), (20, 3), (25, 4), (35, 2), (40, 3)])
+def test_slab_exchange_on_deformed_scenes(built, tmp_path, k, world):
+    """ragged / tiny / wide-window scenes: ranks with few or no frames of their own, every rank must end with the
+    single-process reduced system and solve"""
+    import oracle
+    from tests.helpers import scaled_max_err, vec_err
+    from tests.test_gpu_stress import deformed_problem
+    spec, mk, n = deformed_problem(k)
+    port = 29700 + ((os.getpid() + 7 * k) % 1500)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), {"stress_case": k}, "allgather"), nprocs=world, join=True)
+    ref = oracle.sweep(mk(), radius=1e4, threads=4)
+    so = oracle.solve(mk(), threads=4)
+    r0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    assert abs(float(r0["cost0"]) - ref.cost) <= 1e-11 * ref.cost
+    assert scaled_max_err(r0["S"], ref.S) < 1e-8 and vec_err(r0["rhs"], ref.rhs) < 1e-8
+    assert sum(int(np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))["n_local"]) for r in range(world)) == n
+    for r in range(world):
+        rr = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert (int(rr["it"]), int(rr["term"])) == (so.iterations, so.termination)
+        assert abs(float(rr["final"]) - so.final_cost) <= 1e-7 * so.final_cost
