@@ -1011,8 +1011,12 @@ __global__ __launch_bounds__(256) void k_cost(Dev d, TileSet ts, const CamConsts
       }
     }
   }
+  // one global atomic per WORKGROUP: thousands of atomics on one address serialise in L2 (they were most of this kernel's time)
+  __shared__ double part[4];
   cost = wave_sum(cost);
-  if (lane == 0) atomicAdd(cost_out, cost);
+  if (lane == 0) part[threadIdx.x >> 6] = cost;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(cost_out, part[0] + part[1] + part[2] + part[3]);
 }
 
 // reprojection statistics (reference src/CameraCalibration.cpp:1026-1103): out = {sum ex^2, sum ey^2, n, inliers}, max as bits
@@ -1051,10 +1055,14 @@ __global__ __launch_bounds__(256) void k_stats(Dev d, TileSet ts, const CamConst
   sx = wave_sum(sx); sy = wave_sum(sy); n = wave_sum(n); inl = wave_sum(inl);
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) { mx = fmax(mx, __shfl_xor(mx, m, 64)); my = fmax(my, __shfl_xor(my, m, 64)); }
-  if (lane == 0) {
-    atomicAdd(sums + 0, sx); atomicAdd(sums + 1, sy); atomicAdd(sums + 2, n); atomicAdd(sums + 3, inl);
-    atomicMax(maxbits + 0, (unsigned long long)__double_as_longlong(mx));
-    atomicMax(maxbits + 1, (unsigned long long)__double_as_longlong(my));
+  // one set of global atomics per WORKGROUP (same-address atomics serialise in L2)
+  __shared__ double part[4][6];
+  if (lane == 0) { double* q = part[threadIdx.x >> 6]; q[0] = sx; q[1] = sy; q[2] = n; q[3] = inl; q[4] = mx; q[5] = my; }
+  __syncthreads();
+  if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+  else if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    atomicMax(maxbits + (k - 4), (unsigned long long)__double_as_longlong(fmax(fmax(part[0][k], part[1][k]), fmax(part[2][k], part[3][k]))));
   }
 }
 

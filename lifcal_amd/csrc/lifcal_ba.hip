@@ -294,7 +294,7 @@ int launch_candidate(lifcal_ba_handle* h) {
   const double* pts_eval = d.use_points ? d.pts_c : d.pts;
   for (const TileSet* ts : {&h->ts1, &h->ts2}) {
     if (!ts->n_tiles) continue;
-    const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 2048u));
+    const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 1024u));
 #define CALL_COST(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)d.camc_c, (const double*)d.ft_c, (const double*)d.lt_c, pts_eval, h->partial + 4)
     DISPATCH_CFG(h, CALL_COST);
 #undef CALL_COST
@@ -907,7 +907,7 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
           const double* pts_eval = d.use_points ? d.pts_c : d.pts;
           for (const TileSet* ts : {&h->ts1, &h->ts2}) {
             if (!ts->n_tiles) continue;
-            const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 2048u));
+            const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 1024u));
 #define CALL_COST2(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)d.camc_c, (const double*)d.ft_c, (const double*)d.lt_c, pts_eval, h->partial + 4)
             DISPATCH_CFG(h, CALL_COST2);
 #undef CALL_COST2
@@ -962,7 +962,7 @@ int lifcal_ba_reproj_stats(lifcal_ba_handle* h, double thr, lifcal_ba_stats* out
   HIP_TRY(hipMemsetAsync(h->stats_buf, 0, 8 * sizeof(double), h->stream));
   for (const TileSet* ts : {&h->ts1, &h->ts2}) {
     if (!ts->n_tiles) continue;
-    const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 2048u));
+    const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 1024u));
 #define CALL_STATS(NR, TAN, ADJ) hipLaunchKernelGGL((k_stats<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)h->camc_stats, (const double*)d.ft_c, (const double*)d.lt_c, (const double*)d.pts, thr * thr, h->stats_buf, (unsigned long long*)(h->stats_buf + 4))
     DISPATCH_CFG(h, CALL_STATS);
 #undef CALL_STATS
