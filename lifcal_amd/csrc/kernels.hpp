@@ -918,7 +918,12 @@ __global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by th
     }
   }
   gtd = wave_sum(gtd); ddd = wave_sum(ddd); st2 = wave_sum(st2); x2 = wave_sum(x2);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(partial + 0, gtd); atomicAdd(partial + 1, ddd); atomicAdd(partial + 2, st2); atomicAdd(partial + 3, x2); }
+  // one set of global atomics per workgroup (same-address atomics serialise in L2)
+  __shared__ double part[16][4];
+  const uint32_t wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
+  if ((threadIdx.x & 63) == 0) { part[wv][0] = gtd; part[wv][1] = ddd; part[wv][2] = st2; part[wv][3] = x2; }
+  __syncthreads();
+  if (threadIdx.x < 4) { double t = 0.0; for (uint32_t k = 0; k < nwv; ++k) t += part[k][threadIdx.x]; atomicAdd(partial + threadIdx.x, t); }
 }
 
 // candidate = Plus(x, t * delta) for an arbitrary step length t (ceres ParameterBlock::Plus incl. box projection), from
