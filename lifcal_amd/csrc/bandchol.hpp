@@ -18,7 +18,7 @@ namespace lifcal {
 struct BandLds {
   uint32_t nw, nr4, off_pn, off_d, off_map, off_dummy, total;   // window | panel, component-major (6 x nr4) | L_jj, L_jj^-1, flag | window row of each panel row
   __host__ __device__ BandLds(uint32_t bw, uint32_t NA) {
-    nw = 6 * (bw + 1) + NA + 1;
+    nw = (6 * (bw + 1) + NA + 1) | 1u;   // window dimension AND row stride: odd, so that consecutive rows start on different LDS banks
     nr4 = (nw + 3u) & ~3u;
     off_pn = (nw * nw + 1u) & ~1u; off_d = off_pn + nr4 * 6; off_map = off_d + 80; off_dummy = off_map + (nr4 + 1) / 2 + 1; total = off_dummy + 256;   // ... | one scratch double per thread
   }
@@ -112,7 +112,6 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
     for (int a = 0; a < 6; ++a)
 #pragma unroll
       for (int b = 0; b < 6; ++b) { Li[a * 6 + b] = (b <= a) ? I[a][b] : 0.0; }
-    for (int k = 0; k < 36; ++k) d.Linv[(size_t)jf * 36 + k] = Li[k];
   };
 #ifdef LIFCAL_STAMPS
   unsigned long long cst[6] = {0, 0, 0, 0, 0, 0}, clast = 0;
@@ -129,6 +128,14 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
   };
   uint32_t bi0, bj0;
   tri_block(lane, bi0, bj0);
+  const bool pf_ok = (R * 36 <= 512) && (NAx * 6 <= 256);
+  double pfn[3] = {0.0, 0.0, 0.0};
+  auto fetch_frame = [&](uint32_t f) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { const uint32_t t = lane + 256 * q; if (t < R * 36) pfn[q] = d.Sband[((size_t)f * (bw + 1) + t / 36) * 36 + t % 36]; }
+    if (lane < NAx * 6) pfn[2] = d.Sarrow[(size_t)(lane / 6) * ld + 6 * f + lane % 6];
+  };
+  if (pf_ok && R < F) fetch_frame(R);
   // ---- the chain over the pose blocks ----
   // (barriers inside the chain order LDS only: __syncthreads() would also wait for the panel / L^-1 stores on their way to
   // HBM — a write round trip per barrier, four per pose block — and nothing in the chain reads them back)
@@ -142,6 +149,7 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
     const uint32_t nbel = min(bw, F - 1 - j);
     const uint32_t nrows = 6 * nbel + NAx;
     double* Lp = Lpanel + (size_t)j * (6 * bw + NAx) * 6;
+    if (lane >= 192 && lane < 228) d.Linv[(size_t)j * 36 + (lane - 192)] = Li[lane - 192];   // L_jj^-1 to HBM for the back-substitution: 36 lanes, off the factoring lane's path
     for (uint32_t r = lane; r < nrows; r += 256) {
       const uint32_t wrow = (r < 6 * nbel) ? slot(j + 1 + r / 6) + r % 6 : arow0 + (r - 6 * nbel);
       wmap[r] = wrow;
@@ -159,17 +167,13 @@ __global__ __launch_bounds__(256) void k_band_chol_w(Dev d, double* Lpanel) {
     }
     CSTAMP(2);
     lds_barrier();
-    // the frame that enters the ring after this step: issue its HBM loads now, commit them to LDS after the update
+    // the frame that enters the ring after this step was requested from HBM ONE STEP AGO (pfn); the request for the frame
+    // of the next step goes out now — a step is shorter than the HBM round trip
     // (up to 2 band values + 1 arrow value per thread for bw <= 13; wider bands take the plain path below)
     const bool has_next = (j + R < F);
-    const bool pf = has_next && (R * 36 <= 512) && (NAx * 6 <= 256);
-    double pfv[3] = {0.0, 0.0, 0.0};
-    if (pf) {
-      const uint32_t f = j + R;
-#pragma unroll
-      for (int q = 0; q < 2; ++q) { const uint32_t t = lane + 256 * q; if (t < R * 36) pfv[q] = d.Sband[((size_t)f * (bw + 1) + t / 36) * 36 + t % 36]; }
-      if (lane < NAx * 6) pfv[2] = d.Sarrow[(size_t)(lane / 6) * ld + 6 * f + lane % 6];
-    }
+    const bool pf = has_next && pf_ok;
+    double pfv[3] = {pfn[0], pfn[1], pfn[2]};
+    if (pf_ok && j + 1 + R < F) fetch_frame(j + 1 + R);
     // rank-6 update of the window in 4x4 blocks of (panel row, panel row) pairs over the lower triangle, one block per
     // thread.  The phase is bound by LDS traffic: the panel is stored component-major (Pn[k][row]) so that the four rows of
     // a block are one 32-byte run per component (12 + 12 ds_read_b128 for 96 MACs, no bank-conflicting 48-byte strides),

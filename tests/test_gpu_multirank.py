@@ -110,7 +110,7 @@ def test_ranks_match_the_single_process_oracle(built, tmp_path, spec_kw, mode, w
     assert abs(float(r0["stats"][0]) - stt.std_x) < 1e-9 and int(r0["stats"][2]) == sc.n_obs
 
 
-@pytest.mark.parametrize("k,world", [(10, 2), (20, 3), (25, 4), (35, 2), (40, 3)])
+@pytest.mark.parametrize("k,world", [(11, 2), (22, 3), (26, 4), (37, 2), (41, 3)])   # (multiples of 5 are the big scenes of the family: too slow for the oracle here)
 def test_slab_exchange_on_deformed_scenes(built, tmp_path, k, world):
     """ragged / tiny / wide-window scenes: ranks with few or no frames of their own, every rank must end with the
     single-process reduced system and solve"""

@@ -66,7 +66,7 @@ def test_random_structures_match_the_oracle(built, chunk):
         assert vec_err(got.point_gradient, ref.point_gradient) < 1e-9, tag
 
 
-@pytest.mark.parametrize("k", [1, 4, 6, 9, 12, 15, 18, 21, 27, 33, 36, 45])
+@pytest.mark.parametrize("k", [1, 4, 6, 9, 12, 16, 18, 21, 27, 33, 36, 46])   # small members of the family (k % 5 != 0): the oracle solves them in well under a second
 def test_random_structures_solve_like_the_oracle(built, k):
     spec, mk, n = deformed_problem(k)
     if n < 30:
