@@ -245,7 +245,6 @@ __global__ __launch_bounds__(256) void k_sweep(Dev d) {
     }
 
     if (cnt > 0 && d.use_poses) {
-      const uint32_t F6 = 6 * d.F;
       const double Am[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
       // Gr = [e_x x Y, (0,c0,s0) x Y, R[:,2] x Y]
       const double n0 = R[2], n1 = R[5], n2 = R[8];

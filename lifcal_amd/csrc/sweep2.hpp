@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
 
   STAMP(14);
   for (uint32_t ps = ps_begin; ps < ps_end; ++ps) {
-    const uint32_t np = __builtin_amdgcn_readfirstlane(nx_np), gid0 = __builtin_amdgcn_readfirstlane(nx_gid0);
+    const uint32_t np = __builtin_amdgcn_readfirstlane(nx_np);
     const uint32_t si = nx_si, pt = nx_pt, row0 = nx_row0, kmax = nx_row1 - nx_row0;
     const uint32_t fp = nx_fp;
     // Jacobi scales for the factor phase: requested now, consumed after the observation loop
@@ -233,7 +233,6 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     // ---------------- phase 1: observations -> LDS blocks ----------------
     {
       const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = (si >> 16) & 0xFFu, rep = (si >> 24) % lay.nrep;
-      const uint32_t g = lane * 4 + w;
       const uint32_t fr = flo + lf;
       double R[9], Y[3], c0, s0;
       GroupConsts2 gcn;

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
 
     STAMP(14);
     for (uint32_t ps = ps_begin; ps < ps_end; ++ps) {
-      const uint32_t np = __builtin_amdgcn_readfirstlane(nx_np), gid0 = __builtin_amdgcn_readfirstlane(nx_gid0);
+      const uint32_t np = __builtin_amdgcn_readfirstlane(nx_np);
       const uint32_t si = nx_si, pt = nx_pt, fp = nx_fp, gidx = nx_gid;
       const uint32_t row0 = __builtin_amdgcn_readfirstlane(nx_r[0]), kmax = __builtin_amdgcn_readfirstlane(nx_r[1]) - row0;
       double fsg0 = 1.0, fsg1 = 1.0, fsg2 = 1.0;
@@ -253,8 +253,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       STAMP(13);
       lds_barrier();                                                                                    // ---- barrier P1
       STAMP(0);
-      const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = (si >> 16) & 0xFFu, rep = (si >> 24) % lay.nrep;
-      const uint32_t g = lane * 4 + wl;
+      const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = (si >> 16) & 0xFFu;
       const uint32_t fr = flo + lf;
       GroupConsts2 gcn;
       {
@@ -355,7 +354,6 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < 3; ++j) GAG[i][j] = Gr[0][i] * AG[0][j] + Gr[1][i] * AG[1][j] + Gr[2][i] * AG[2][j];
-        (void)rep;
         const RunMask rm = run_masks(cnt, lf);
         double* fr_acc = Fr + lf;
         {
@@ -517,7 +515,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       zero_slab();
       lds_barrier();                                                                                    // ---- barrier P1
       STAMPB(0);
-      const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = (si >> 16) & 0xFFu, rep = (si >> 24) % lay.nrep;
+      const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = (si >> 16) & 0xFFu;
       double C[3][NC];
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -572,7 +570,6 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < NC; ++j) C[i][j] *= c.chm[j];   // sign/scale folding and free-column mask, once per lane
-        (void)rep;
         const RunMask rm = run_masks(cnt, lf);
         double* fr_acc = Fr + lf;
 #pragma unroll
