@@ -20,7 +20,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("lifcal_oracle.cpp", "model.hpp", "jet.hpp", "lifcal_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("lifcal_oracle.cpp", "lifcal_mla.cpp", "model.hpp", "jet.hpp", "lifcal_oracle.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "lifcal_ba.h"))
     stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if stale:

@@ -25,6 +25,23 @@ int lo_reproj_stats(const lifcal_ba_problem* p, double thr, lifcal_ba_stats* out
 int lo_hardware_threads(void);
 /* reference src/CameraCalibration.cpp:456-499 (initPlenopticParameters), JacobiSVD restated as a one-sided Jacobi SVD */
 int lo_init_plenoptic(const lifcal_init_problem* p, lifcal_init_result* out);
+
+/* ---- oracle/lifcal_mla.cpp: micro-lens grid, lens maps, epipolar web, projection of virtual-image points into the micro
+ * images (reference src/MicroLensGrid/MicroLensGrid.cpp:186-270, :338-421; src/CameraCalibration.cpp:521-632, :637-769) */
+typedef struct lo_mla_params {
+  int32_t width, height;             /* raw image size */
+  float lens_diameter, lens_base_y[2], rotation, offset[2];   /* <diam>, <lens_base_y>, <rotation>, <offset> of the MLA file */
+  int32_t rotation_on_grid;          /* readInGrid(..., doRotationOnGrid) */
+} lo_mla_params;
+void* lo_mla_create(const lo_mla_params* p);
+void lo_mla_destroy(void* h);
+int lo_mla_counts(void* h, int32_t* n_lenses, int32_t* n_web_groups, int32_t* n_web_lines);
+int lo_mla_lenses(void* h, float* cx, float* cy, int32_t* type);
+int lo_mla_maps(void* h, int32_t* map_ml, int32_t* map_next);          /* lens index or -1 per raw pixel */
+int lo_mla_web(void* h, double* dist, double* ex, double* ey, int32_t* group);
+/* one frame of projectPointsToRawImage; returns the observation count, or -(needed) when capacity is too small */
+int64_t lo_mla_project_frame(void* h, int32_t depth_to_raw_im_scale, int64_t n, const double* px, const double* py, const double* vd,
+                             int64_t capacity, double* xR, double* yR, double* cX, double* cY, int64_t* point);
 #ifdef __cplusplus
 }
 #endif
