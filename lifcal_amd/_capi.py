@@ -108,6 +108,35 @@ class InitArrays:
                                   as_dptr(self.w2c), as_dptr(self.pts), float(fL_init))
 
 
+class MlaParams(C.Structure):      # include/lifcal_mla.h lifcal_mla_params
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("lens_diameter", C.c_float), ("lens_base_y", C.c_float * 2),
+                ("rotation", C.c_float), ("offset", C.c_float * 2), ("rotation_on_grid", C.c_int32)]
+
+
+class MlaPoints(C.Structure):      # lifcal_mla_points
+    _fields_ = [("n", C.c_uint64), ("x", dptr), ("y", dptr), ("vdepth", dptr), ("fr", uptr), ("pt", uptr)]
+
+
+class MlaObservations(C.Structure):  # lifcal_mla_observations
+    _fields_ = [("capacity", C.c_uint64), ("n_obs", C.c_uint64), ("u", dptr), ("v", dptr), ("mcx", dptr), ("mcy", dptr),
+                ("src", uptr), ("fr", uptr), ("pt", uptr)]
+
+
+MLA_MORE = 1
+_fptr = C.POINTER(C.c_float)
+_iptr = C.POINTER(C.c_int32)
+
+# every symbol include/lifcal_mla.h declares
+MLA_PROTOTYPES = {
+    "lifcal_mla_create": (C.c_int, [C.POINTER(MlaParams), C.c_int32, C.POINTER(C.c_void_p)]),
+    "lifcal_mla_destroy": (None, [C.c_void_p]),
+    "lifcal_mla_info": (C.c_int, [C.c_void_p, _iptr, _iptr, _iptr]),
+    "lifcal_mla_get_lenses": (C.c_int, [C.c_void_p, _fptr, _fptr, _iptr]),
+    "lifcal_mla_get_maps": (C.c_int, [C.c_void_p, _iptr, _iptr]),
+    "lifcal_mla_get_web": (C.c_int, [C.c_void_p, dptr, dptr, dptr, _iptr]),
+    "lifcal_mla_project": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(MlaPoints), C.POINTER(MlaObservations)]),
+}
+
 # every symbol include/lifcal_ba.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     "lifcal_ba_default_options": (None, [C.POINTER(Options)]),
@@ -146,7 +175,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback for the bundle-adjustment path.")
         lib = C.CDLL(path)
-        for name, (res, args) in PROTOTYPES.items():
+        for name, (res, args) in list(PROTOTYPES.items()) + list(MLA_PROTOTYPES.items()):
             fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args

@@ -984,3 +984,6 @@ int lifcal_ba_reproj_stats(lifcal_ba_handle* h, double thr, lifcal_ba_stats* out
 }
 
 }  // extern "C"
+
+// micro-lens grid, lens maps, epipolar web and projectPointsToRawImage (include/lifcal_mla.h)
+#include "mla.hpp"

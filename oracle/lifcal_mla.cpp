@@ -270,6 +270,8 @@ int64_t lo_mla_project_frame(void* h, int32_t depth_to_raw_im_scale, int64_t n, 
     float radius_2 = radius * radius;
     float xUps_flt = ((float)depth_to_raw_im_scale) * (x + 0.5f) - 0.5f;
     float yUps_flt = ((float)depth_to_raw_im_scale) * (y + 0.5f) - 0.5f;
+    // (not in the reference: coordinates a float cannot carry into an int are outside its contract; no observation)
+    if (!(xUps_flt > -1.0e9f && xUps_flt < 1.0e9f && yUps_flt > -1.0e9f && yUps_flt < 1.0e9f)) continue;
     int xUps_int = (int)(xUps_flt + 0.5f);
     if (xUps_int >= rawWidth) xUps_int = rawWidth - 1;
     int yUps_int = (int)(yUps_flt + 0.5f);

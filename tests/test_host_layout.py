@@ -22,6 +22,11 @@ def test_library_exports_every_declared_symbol(built):
     for name in sorted(declared):
         assert hasattr(lib, name), f"{name} declared in include/lifcal_ba.h but not exported"
     assert declared == set(capi.PROTOTYPES), (declared ^ set(capi.PROTOTYPES))
+    hdr2 = open(os.path.join(ROOT, "include", "lifcal_mla.h")).read()
+    declared2 = set(re.findall(r"\b(lifcal_mla_[a-z_0-9]+)\s*\(", hdr2))
+    assert declared2 == set(capi.MLA_PROTOTYPES), (declared2 ^ set(capi.MLA_PROTOTYPES))
+    for name in sorted(declared2):
+        assert hasattr(lib, name), f"{name} declared in include/lifcal_mla.h but not exported"
     assert b"gfx950" in lib.lifcal_ba_version()
 
 
