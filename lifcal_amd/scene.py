@@ -263,6 +263,13 @@ class Scene:
     c_sigma: np.ndarray
     use_constraints: int
     n_lenses: int
+    # the virtual-image points the observations were made from (what projectPointsToRawImage consumes), frame-major:
+    # image coordinates in virtual-image pixels, virtual depth, frame and object-point index
+    img_x: Optional[np.ndarray] = None
+    img_y: Optional[np.ndarray] = None
+    img_vd: Optional[np.ndarray] = None
+    img_fr: Optional[np.ndarray] = None
+    img_pt: Optional[np.ndarray] = None
 
     @property
     def n_obs(self) -> int:
@@ -416,4 +423,11 @@ def make_scene(spec: SceneSpec) -> Scene:
         c_i=c_i, c_j=c_j, c_dist=c_dist, c_sigma=c_sigma,
         use_constraints=0 if spec.recalib else 1,
         n_lenses=int(lenses.shape[0]),
+        **_image_points(pf_p, pf_f, x_ups, y_ups, vdn, spec.scale),
     )
+
+
+def _image_points(pf_p, pf_f, x_ups, y_ups, vdn, scale):
+    order = np.lexsort((pf_p, pf_f))
+    return dict(img_x=(x_ups[order] + 0.5) / scale - 0.5, img_y=(y_ups[order] + 0.5) / scale - 0.5, img_vd=vdn[order].copy(),
+                img_fr=pf_f[order].astype(np.uint32), img_pt=pf_p[order].astype(np.uint32))
