@@ -203,6 +203,10 @@ int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out);
 
 /* replaces reference :1026-1103 (evaluated on the device-resident parameters) */
 int lifcal_ba_reproj_stats(lifcal_ba_handle* h, double inlier_threshold, lifcal_ba_stats* out);
+/* The x_proj / y_proj columns of reference storeRawImagePointsCsv (:1504-1538): the model's projection of every observation at
+ * the stored parameters, [n_obs] host arrays in the caller's observation order, evaluated as reproj_stats evaluates it.
+ * With world_size > 1 a rank fills the observations of the points it owns and leaves NaN elsewhere. */
+int lifcal_ba_project_observations(lifcal_ba_handle* h, double* x_proj, double* y_proj);
 
 /* re-upload cam/views/pts from the caller's arrays (e.g. to re-run from a new initial point) */
 int lifcal_ba_upload_parameters(lifcal_ba_handle* h);

@@ -137,6 +137,27 @@ MLA_PROTOTYPES = {
     "lifcal_mla_project": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(MlaPoints), C.POINTER(MlaObservations)]),
 }
 
+class CameraModel(C.Structure):    # include/lifcal_io.h lifcal_camera_model
+    _fields_ = [("image_width", C.c_int32), ("image_height", C.c_int32), ("pixel_size", C.c_double),
+                ("fL", C.c_double), ("bL0", C.c_double), ("B", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("n_radial", C.c_int32), ("radial", C.c_double * 8), ("tangential", C.c_int32), ("tangential_dist", C.c_double * 2),
+                ("ml_center_adjustment", C.c_int32)]
+
+
+class Protocol(C.Structure):       # lifcal_protocol
+    _fields_ = [("model", CameraModel), ("refine_poses", C.c_int32), ("refine_points", C.c_int32), ("robust_cost", C.c_int32),
+                ("std_x", C.c_double), ("std_y", C.c_double), ("mae_x", C.c_double), ("mae_y", C.c_double)]
+
+
+# every symbol include/lifcal_io.h declares
+IO_PROTOTYPES = {
+    "lifcal_write_camera_model": (C.c_int, [C.c_char_p, C.POINTER(CameraModel)]),
+    "lifcal_write_extrinsic_orientations_xml": (C.c_int, [C.c_char_p, C.c_uint32, _iptr, dptr]),
+    "lifcal_write_extrinsic_orientations_txt": (C.c_int, [C.c_char_p, C.c_uint32, _iptr, dptr]),
+    "lifcal_write_raw_image_points_csv": (C.c_int, [C.c_char_p, C.c_uint64, _iptr, uptr, dptr, dptr, dptr, dptr, uptr]),
+    "lifcal_write_protocol": (C.c_int, [C.c_char_p, C.POINTER(Protocol)]),
+}
+
 # every symbol include/lifcal_ba.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     "lifcal_ba_default_options": (None, [C.POINTER(Options)]),
@@ -147,6 +168,7 @@ PROTOTYPES = {
     "lifcal_ba_profile_begin": (C.c_int, [C.c_void_p, C.c_uint32]),
     "lifcal_ba_profile_end": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "lifcal_ba_reproj_stats": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(Stats)]),
+    "lifcal_ba_project_observations": (C.c_int, [C.c_void_p, dptr, dptr]),
     "lifcal_ba_upload_parameters": (C.c_int, [C.c_void_p]),
     "lifcal_ba_download_parameters": (C.c_int, [C.c_void_p]),
     "lifcal_ba_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),
@@ -175,7 +197,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback for the bundle-adjustment path.")
         lib = C.CDLL(path)
-        for name, (res, args) in list(PROTOTYPES.items()) + list(MLA_PROTOTYPES.items()):
+        for name, (res, args) in list(PROTOTYPES.items()) + list(MLA_PROTOTYPES.items()) + list(IO_PROTOTYPES.items()):
             fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args

@@ -87,6 +87,14 @@ class BundleAdjustment:
         _check(self.lib, self.lib.lifcal_ba_reproj_stats(self._h, inlierThreshold, C.byref(st)), "lifcal_ba_reproj_stats")
         return st
 
+    def projectObservations(self):
+        """(x_proj, y_proj) per observation at the stored parameters, in the caller's observation order — the projected
+        columns of reference storeRawImagePointsCsv (src/CameraCalibration.cpp:1504-1538)."""
+        n = self.problem.struct.n_obs
+        x = np.zeros(n); y = np.zeros(n)
+        _check(self.lib, self.lib.lifcal_ba_project_observations(self._h, capi.as_dptr(x), capi.as_dptr(y)), "lifcal_ba_project_observations")
+        return x, y
+
     # -- the benchmarked unit ------------------------------------------------------------------
     def sweep(self, radius: float = 1e4, want_matrices: bool = False):
         """One Jacobian+Schur sweep; returns a namespace with cost, gradient_max_norm, seconds and,

@@ -1023,6 +1023,41 @@ __global__ __launch_bounds__(256) void k_cost(Dev d, TileSet ts, const CamConsts
   if (threadIdx.x == 0) atomicAdd(cost_out, part[0] + part[1] + part[2] + part[3]);
 }
 
+// projected micro-image coordinates of every observation at the stored parameters, scattered back to the caller's
+// observation order (reference storeRawImagePointsCsv, src/CameraCalibration.cpp:1504-1538: x_proj, y_proj columns)
+template <int NR, bool TAN, bool ADJ>
+__global__ __launch_bounds__(256) void k_project_obs(Dev d, TileSet ts, const uint32_t* __restrict__ src, const CamConsts* camc, const double* ft_tab,
+                                                     const double* lt_tab, const double* pts, double* __restrict__ xp, double* __restrict__ yp) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+  const CamConsts c = *camc;
+  for (uint32_t tile = wave; tile < ts.n_tiles; tile += n_waves) {
+    const uint32_t slot = tile * 64 + lane;
+    const uint32_t cnt = ts.slot_cnt[slot];
+    const uint32_t row0 = ts.tile_row0[tile], kmax = ts.tile_row0[tile + 1] - row0;
+    const double* ft = ft_tab + (size_t)ts.slot_fr[slot] * FRAME_STRIDE;
+    const double* P = pts + 3 * (size_t)ts.slot_pt[slot];
+    GroupConsts g;
+    {
+      const double P0 = P[0], P1 = P[1], P2 = P[2];
+      group_prepare(c, ft[0] * P0 + ft[1] * P1 + ft[2] * P2 + ft[9], ft[3] * P0 + ft[4] * P1 + ft[5] * P2 + ft[10],
+                    ft[6] * P0 + ft[7] * P1 + ft[8] * P2 + ft[11], g);
+    }
+    for (uint32_t k = 0; k < kmax; ++k) {
+      if (k < cnt) {
+        const size_t at = ((size_t)row0 + k) * 64 + lane;
+        const double* L = lt_tab + (size_t)ts.ell_lens[at] * LENS_STRIDE;
+        double ex, ey;
+        const double u = ts.ell_u[at], v = ts.ell_v[at];
+        obs_value<NR, TAN, ADJ>(c, g, L[0], L[1], L[2], L[3], u, v, ex, ey);
+        const uint32_t i = src[at];
+        xp[i] = ex + u; yp[i] = ey + v;
+      }
+    }
+  }
+}
+
 // reprojection statistics (reference src/CameraCalibration.cpp:1026-1103): out = {sum ex^2, sum ey^2, n, inliers}, max as bits
 template <int NR, bool TAN, bool ADJ>
 __global__ __launch_bounds__(256) void k_stats(Dev d, TileSet ts, const CamConsts* camc, const double* ft_tab, const double* lt_tab,

@@ -983,7 +983,52 @@ int lifcal_ba_reproj_stats(lifcal_ba_handle* h, double thr, lifcal_ba_stats* out
   return 0;
 }
 
+// x_proj / y_proj of reference storeRawImagePointsCsv (src/CameraCalibration.cpp:1504-1538): the model's projection of every
+// observation at the stored parameters, evaluated like calcReprojectionError evaluates it (:1028-1039)
+int lifcal_ba_project_observations(lifcal_ba_handle* h, double* x_proj, double* y_proj) {
+  if (!h || !x_proj || !y_proj) return LIFCAL_BA_ERR_INVALID_ARG;
+  Dev& d = h->d;
+  const Plan& L = h->plan;
+  const size_t n = h->prob.n_obs;
+  if (n == 0) return 0;
+  HIP_TRY(hipSetDevice(h->opt.device));
+  if (int rc = launch_tables(h, d.cam, d.views, h->camc_stats, d.ft_c, d.lt_c, false, false)) return rc;
+  uint32_t *src1 = nullptr, *src2 = nullptr; double* out = nullptr;
+  auto release = [&]() { for (void* q : {(void*)src1, (void*)src2, (void*)out}) if (q) (void)hipFree(q); };
+  auto up = [&](uint32_t** q, const std::vector<uint32_t>& v) -> hipError_t {
+    if (v.empty()) return hipSuccess;
+    hipError_t e = hipMalloc((void**)q, v.size() * 4);
+    return e == hipSuccess ? hipMemcpyAsync(*q, v.data(), v.size() * 4, hipMemcpyHostToDevice, h->stream) : e;
+  };
+  hipError_t e = up(&src1, L.ell_src);
+  if (e == hipSuccess) e = up(&src2, L.v2_src);
+  if (e == hipSuccess) e = hipMalloc((void**)&out, 2 * n * 8);
+  if (e == hipSuccess) e = hipMemsetAsync(out, 0xff, 2 * n * 8, h->stream);   // NaN where another rank owns the observation
+  if (e == hipSuccess) {
+    const TileSet* sets[2] = {&h->ts1, &h->ts2};
+    const uint32_t* srcs[2] = {src1, src2};
+    for (int k = 0; k < 2; ++k) {
+      const TileSet* ts = sets[k];
+      if (!ts->n_tiles || !srcs[k]) continue;
+      const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 1024u));
+#define CALL_PROJ(NR, TAN, ADJ) hipLaunchKernelGGL((k_project_obs<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, srcs[k], (const CamConsts*)h->camc_stats, (const double*)d.ft_c, (const double*)d.lt_c, (const double*)d.pts, out, out + n)
+      DISPATCH_CFG(h, CALL_PROJ);
+#undef CALL_PROJ
+    }
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(x_proj, out, n * 8, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(y_proj, out + n, n * 8, hipMemcpyDeviceToHost, h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+  release();
+  if (e != hipSuccess) { g_last_error = std::string("lifcal_ba_project_observations: ") + hipGetErrorString(e); return LIFCAL_BA_ERR_HIP; }
+  return 0;
+}
+
 }  // extern "C"
 
 // micro-lens grid, lens maps, epipolar web and projectPointsToRawImage (include/lifcal_mla.h)
 #include "mla.hpp"
+
+// LiFCal's result files (include/lifcal_io.h)
+#include "writers.hpp"

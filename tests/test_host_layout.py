@@ -27,6 +27,11 @@ def test_library_exports_every_declared_symbol(built):
     assert declared2 == set(capi.MLA_PROTOTYPES), (declared2 ^ set(capi.MLA_PROTOTYPES))
     for name in sorted(declared2):
         assert hasattr(lib, name), f"{name} declared in include/lifcal_mla.h but not exported"
+    hdr3 = open(os.path.join(ROOT, "include", "lifcal_io.h")).read()
+    declared3 = set(re.findall(r"\b(lifcal_write_[a-z_0-9]+)\s*\(", hdr3))
+    assert declared3 == set(capi.IO_PROTOTYPES), (declared3 ^ set(capi.IO_PROTOTYPES))
+    for name in sorted(declared3):
+        assert hasattr(lib, name), f"{name} declared in include/lifcal_io.h but not exported"
     assert b"gfx950" in lib.lifcal_ba_version()
 
 

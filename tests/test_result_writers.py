@@ -1,0 +1,105 @@
+"""LiFCal's result files (include/lifcal_io.h) against the formats the reference writes (src/CameraCalibration.cpp:1296-1617):
+pugixml's default layout with boost::lexical_cast numbers (17 significant digits, %g style), "%05d" + 16 x " %16.10f",
+"%d,%d,%f,%f,%f,%f,%d", and the protocol text.  Host code: runs without a GPU."""
+import math
+import xml.etree.ElementTree as ET
+
+import numpy as np
+import pytest
+
+from lifcal_amd import results, scene
+from lifcal_amd.bundle_adjustment import LifcalError
+
+
+def _num(v):
+    return "%.17g" % v
+
+
+CAM = [35.01234567890123, 34.15, 0.4, 511.3, 513.9, 5e-5, -2e-7, 1e-5, -1e-5] + [0.0] * 8
+
+
+def test_camera_model_xml(tmp_path, built):
+    m = results.camera_model((1024, 1024), 0.011, CAM, 0xF06)
+    results.storeCameraModel(str(tmp_path), m)
+    text = (tmp_path / "CameraModel.xml").read_text()
+    expect = ('<?xml version="1.0" encoding="UTF-8"?>\n<Root>\n\t<CalibrationModel>Plenoptic</CalibrationModel>\n'
+              '\t<ImageSize units="pix">\n\t\t<Width>1024</Width>\n\t\t<Height>1024</Height>\n\t</ImageSize>\n'
+              '\t<PixelSize units="mm">0.01100</PixelSize>\n'
+              f'\t<PrincipalPoint units="pix">\n\t\t<x>{_num(511.3)}</x>\n\t\t<y>{_num(513.9)}</y>\n\t</PrincipalPoint>\n'
+              f'\t<FocalLength units="mm">{_num(CAM[0])}</FocalLength>\n'
+              f'\t<MainLensMlaDistance units="mm">{_num(34.15)}</MainLensMlaDistance>\n'
+              f'\t<SensorMlaDistance units="mm">{_num(0.4)}</SensorMlaDistance>\n'
+              f'\t<RadialDistortion units="mm">\n\t\t<A0>{_num(5e-5)}</A0>\n\t\t<A1>{_num(-2e-7)}</A1>\n\t</RadialDistortion>\n'
+              f'\t<TangentialDistortion units="mm">\n\t\t<B0>{_num(1e-5)}</B0>\n\t\t<B1>{_num(-1e-5)}</B1>\n\t</TangentialDistortion>\n'
+              '\t<MicroLensCenterAdjustment>true</MicroLensCenterAdjustment>\n</Root>\n')
+    assert text == expect
+    root = ET.fromstring(text)                                       # what a consumer reads back is the double itself
+    assert float(root.find("FocalLength").text) == CAM[0] and float(root.find("SensorMlaDistance").text) == 0.4
+    assert "0.40000000000000002" in text                             # lexical_cast prints 17 significant digits
+
+
+def test_camera_model_without_distortion(tmp_path, built):
+    results.storeCameraModel(str(tmp_path), results.camera_model((640, 480), 0.0055, CAM, 0x500))
+    root = ET.parse(tmp_path / "CameraModel.xml").getroot()
+    assert root.find("RadialDistortion") is None and root.find("TangentialDistortion") is None
+    assert root.find("MicroLensCenterAdjustment").text == "false" and root.find("PixelSize").text == "0.00550"
+    assert [c.tag for c in root] == ["CalibrationModel", "ImageSize", "PixelSize", "PrincipalPoint", "FocalLength", "MainLensMlaDistance",
+                                     "SensorMlaDistance", "MicroLensCenterAdjustment"]
+
+
+def test_extrinsic_orientations(tmp_path, built):
+    views = np.array([[0.1, -0.2, 0.3, 10.0, -20.5, 1 / 3], [0.0, 0.0, 0.0, 0.0, 0.0, 0.0], [-1.2, 0.7, 2.9, 1e-3, 1e6, -7.25]])
+    ids = [12, 3, 100007]
+    results.storeExtrinsicOrientations(str(tmp_path), ids, views)
+    text = (tmp_path / "extrinsicOrientations.xml").read_text()
+    assert text.startswith('<?xml version="1.0" encoding="UTF-8"?>\n<Root>\n\t<Frame id="12">\n\t\t<Rotation>\n\t\t\t<Coeff i="0">' + _num(0.1) + "</Coeff>\n")
+    root = ET.fromstring(text)
+    frames = root.findall("Frame")
+    assert [f.get("id") for f in frames] == ["12", "3", "100007"]                  # file order = frame order, not sorted
+    for f, v in zip(frames, views):
+        assert [float(c.text) for c in f.find("Rotation")] == list(v[:3])
+        assert [float(c.text) for c in f.find("Translation")] == list(v[3:])
+        assert [c.get("i") for c in f.find("Translation")] == ["0", "1", "2"]
+    results.storeExtrinsicOrientationsTxt(str(tmp_path), ids, views)
+    lines = (tmp_path / "ExtrinsicOrientations.txt").read_text().splitlines()
+    assert [l.split()[0] for l in lines] == ["00003", "00012", "100007"]
+    R = scene.euler_xyz(views[:, :3])
+    for line, k in zip(lines, [1, 0, 2]):                                          # sorted by frame id (:1456)
+        m = np.eye(4); m[:3, :3] = R[k]; m[:3, 3] = views[k, 3:]
+        assert line == "%05d" % ids[k] + "".join(" %16.10f" % x for x in m.reshape(-1))
+
+
+def test_raw_image_points_csv(tmp_path, built):
+    fr = np.array([0, 0, 0, 2, 2, 3], np.uint32)
+    ids = [7, 8, 9, 11]
+    u = np.array([1.5, 2.25, 1000.123456789, 4, 5, 6.0]); v = u + 0.5
+    xp = u + 0.001; yp = v - 0.002
+    pt = np.array([5, 6, 5, 0, 9, 3], np.uint32)
+    results.storeRawImagePointsCsv(str(tmp_path), ids, fr, u, v, xp, yp, pt)
+    lines = (tmp_path / "rawImagePoints.csv").read_text().splitlines()
+    within = [0, 1, 2, 0, 1, 0]                                                    # index inside the frame (:1512)
+    for k, line in enumerate(lines):
+        assert line == "%d,%d,%f,%f,%f,%f,%d" % (ids[fr[k]], within[k], u[k], v[k], xp[k], yp[k], pt[k])
+    assert len(lines) == 6
+    with pytest.raises(LifcalError):
+        results.storeRawImagePointsCsv(str(tmp_path), ids, fr[::-1].copy(), u, v, xp, yp, pt)
+
+
+def test_protocol(tmp_path, built):
+    class St: std_x, std_y, mae_x, mae_y = 0.123456789, 0.2, 3.5, 12.25
+    m = results.camera_model((1024, 1024), 0.011, CAM, 0xF06)
+    results.storeProtocol(str(tmp_path), m, 0xF06, St)
+    text = (tmp_path / "calibrationProtocol.txt").read_text()
+    assert text.startswith("*" * 79 + "\n***   LiFCal: Online Light Field Camera Calibration via Bundle Adjustment   ***\n" + "*" * 79 + "\n\n*** Intrinsic Parameters ***\nPixel Size: 0.011 mm\n")
+    assert "\tfL   : %18.15f\n" % CAM[0] in text and "\ta1   : %18.15f\n" % -2e-7 in text and "\tb1   : %18.15f\n" % -1e-5 in text
+    assert "\tDid micro lens center adjustment\n*** Additional Settings ***\n\tDistortion defined on MLA plane.\n\n" in text
+    assert "\tExtrinsic Orientations were refined.\n\n\t3D Object coordinates were refined.\n\n\tRobust cost function was used for estimation.\n\n" in text
+    assert text.endswith("*** Statistics ***\n\tReprojection errors:\n\tstd. Dev. x:            0.12346\n\tstd. Dev. y:            0.20000\n\tmae x:                  3.50000\n\tmae y:                 12.25000\n")
+    results.storeProtocol(str(tmp_path), results.camera_model((1024, 1024), 0.011, CAM, 0x000), 0x000, St)
+    text = (tmp_path / "calibrationProtocol.txt").read_text()
+    assert "COLMAP were kept" in text and "Squared cost function" in text and "a0" not in text and "Did micro" not in text
+
+
+def test_unwritable_path_is_an_error(tmp_path, built):
+    with pytest.raises(LifcalError):
+        results.storeCameraModel(str(tmp_path / "missing_dir"), results.camera_model((1, 1), 1.0, CAM, 0))
