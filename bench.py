@@ -137,7 +137,9 @@ def main():
     o.device = local_rank
     o.rank = rank
     o.world_size = world
+    t_create = time.perf_counter()
     ba = BundleAdjustment(pa, o)
+    t_create = time.perf_counter() - t_create   # planner (host) + upload: once per problem, outside the metric
     if world > 1 and args.comm == "rccl":
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -209,7 +211,7 @@ def main():
             t_solve = time.perf_counter() - t_solve
             after = ba.calcReprojectionError(1.0)
             solve = {"iterations": int(summ.iterations), "successful_steps": int(summ.successful_steps), "termination": int(summ.termination),
-                     "seconds": t_solve, "seconds_in_sweeps": float(summ.seconds_sweep), "seconds_in_linear_solve": float(summ.seconds_linear_solve),
+                     "seconds": t_solve, "create_seconds": t_create, "seconds_in_sweeps": float(summ.seconds_sweep), "seconds_in_linear_solve": float(summ.seconds_linear_solve),
                      "initial_cost": float(summ.initial_cost), "final_cost": float(summ.final_cost),
                      "rms_initial_px": [float(before.std_x), float(before.std_y)],
                      "final_rms_reproj_px": [float(after.std_x), float(after.std_y)],
