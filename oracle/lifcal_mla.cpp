@@ -1,7 +1,7 @@
 // oracle/lifcal_mla.cpp — CPU restatement of the step that turns virtual-image points into micro-image observations
 // (SURVEY.md 8f, rank f1).  TEST INFRASTRUCTURE ONLY, parity unpinned like the rest of oracle/ (see README.md): the product
-// never includes, links or calls this file.  No product code exists for this row yet (DESIGN.md 7b lists the plan); the
-// restatement is here so that the row starts from a checked reference behaviour.
+// never includes, links or calls this file.  It is the sequential, line-by-line checker of the GPU path behind
+// include/lifcal_mla.h (lifcal_amd/csrc/mla.hpp), compared bit for bit in tests/test_gpu_mla.py.
 //
 // Restated line by line, with the reference's types (float / double / int) and evaluation order:
 //   MicroLensGrid::readInGrid      src/MicroLensGrid/MicroLensGrid.cpp:56-170   (derived quantities only, no XML)
