@@ -140,12 +140,51 @@ def main():
     t_create = time.perf_counter()
     ba = BundleAdjustment(pa, o)
     t_create = time.perf_counter() - t_create   # planner (host) + upload: once per problem, outside the metric
+    rccl_ok = True
+    comm_used = args.comm if world > 1 else None
     if world > 1 and args.comm == "rccl":
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).cuda()
-        dist.broadcast(uid, src=0)
-        ba.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()))
+        # the library's own RCCL communicator (ncclAllReduce / ncclAllGather on the solver's stream).  If it cannot be set up on
+        # this node, every rank falls back together to torch.distributed's RCCL group on device buffers (same transport, one
+        # staging copy per call) rather than losing the measurement.
+        try:
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).cuda()
+            dist.broadcast(uid, src=0)
+            ba.comm_init_rccl(bytes(uid.cpu().numpy().tobytes()))
+        except Exception as e:  # noqa: BLE001
+            print(f"[bench rank {rank}] library RCCL communicator failed ({e!r}); falling back to the torch.distributed group", file=sys.stderr)
+            rccl_ok = False
+        flag = torch.tensor([1 if rccl_ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        rccl_ok = bool(flag.item())
+        if not rccl_ok:
+            comm_used = "torch-rccl (fallback)"
+            import ctypes as C
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+            hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+
+            def dev_hook(ptr, count, stream):
+                hip.hipStreamSynchronize(stream)
+                t = torch.empty(count, dtype=torch.float64, device="cuda")
+                hip.hipMemcpy(t.data_ptr(), ptr, count * 8, 3)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()
+                hip.hipMemcpy(ptr, t.data_ptr(), count * 8, 3)
+                return 0
+            ba.set_allreduce(dev_hook)
+
+            def dev_ghook(send, recv, count, stream):
+                hip.hipStreamSynchronize(stream)
+                t = torch.empty(count, dtype=torch.float64, device="cuda")
+                hip.hipMemcpy(t.data_ptr(), send, count * 8, 3)
+                allb = torch.empty(world * count, dtype=torch.float64, device="cuda")
+                dist.all_gather_into_tensor(allb, t)
+                torch.cuda.synchronize()
+                hip.hipMemcpy(recv, allb.data_ptr(), world * count * 8, 3)
+                return 0
+            ba.set_allgather(dev_ghook)
     elif world > 1:
         import ctypes as C
         hip = C.CDLL("libamdhip64.so")
@@ -240,7 +279,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {F_tot} frames, {P_tot} points, {n_obs_total} micro-image observations, "
                                    f"window {spec.window}, config {spec.config:#x} (2 radial + tangential, mlCenterAdj, Cauchy(0.5), refine poses+points)",
-                       "obs_per_gpu": n_loc, "n_reduced": n_red, "sharding": "by 3D point" if world > 1 else "single GPU", "comm": args.comm if world > 1 else None},
+                       "obs_per_gpu": n_loc, "n_reduced": n_red, "sharding": "by 3D point" if world > 1 else "single GPU", "comm": comm_used},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (residual+Jacobian+block accumulation)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
                          "traffic": load_traffic(args.workload),
