@@ -7,7 +7,7 @@
  *   storeExtrinsicOrientationsTxt  :1440-1481   ExtrinsicOrientations.txt  ("%05d" + 16 x " %16.10f", frames sorted by id)
  *   storeRawImagePointsCsv         :1483-1543   rawImagePoints.csv         ("%d,%d,%f,%f,%f,%f,%d")
  *   storeProtocol                  :1545-1617   calibrationProtocol.txt
- * All functions return 0 or LIFCAL_BA_ERR_INVALID_ARG (-1: null argument / file cannot be opened).
+ * All functions return 0, LIFCAL_BA_ERR_INVALID_ARG (-1: null argument / file cannot be opened) or LIFCAL_BA_ERR_OUT_OF_RANGE (-4).
  */
 #ifndef LIFCAL_IO_H
 #define LIFCAL_IO_H
@@ -33,9 +33,9 @@ int lifcal_write_camera_model(const char* path, const lifcal_camera_model* m);
 int lifcal_write_extrinsic_orientations_xml(const char* path, uint32_t n_frames, const int32_t* frame_ids, const double* views);
 int lifcal_write_extrinsic_orientations_txt(const char* path, uint32_t n_frames, const int32_t* frame_ids, const double* views);
 /* One line per observation, frames in order, observations in their order inside the frame (fr must be non-decreasing, as
- * projectPointsToRawImage produces it): frame id, index inside the frame, u, v, x_proj, y_proj (lifcal_ba_project_observations),
+ * projectPointsToRawImage produces it, and below n_frames): frame id, index inside the frame, u, v, x_proj, y_proj (lifcal_ba_project_observations),
  * object-point index. */
-int lifcal_write_raw_image_points_csv(const char* path, uint64_t n_obs, const int32_t* frame_ids, const uint32_t* fr, const double* u,
+int lifcal_write_raw_image_points_csv(const char* path, uint64_t n_obs, uint32_t n_frames, const int32_t* frame_ids, const uint32_t* fr, const double* u,
                                       const double* v, const double* x_proj, const double* y_proj, const uint32_t* pt);
 
 typedef struct lifcal_protocol {

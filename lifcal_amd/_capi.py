@@ -154,7 +154,7 @@ IO_PROTOTYPES = {
     "lifcal_write_camera_model": (C.c_int, [C.c_char_p, C.POINTER(CameraModel)]),
     "lifcal_write_extrinsic_orientations_xml": (C.c_int, [C.c_char_p, C.c_uint32, _iptr, dptr]),
     "lifcal_write_extrinsic_orientations_txt": (C.c_int, [C.c_char_p, C.c_uint32, _iptr, dptr]),
-    "lifcal_write_raw_image_points_csv": (C.c_int, [C.c_char_p, C.c_uint64, _iptr, uptr, dptr, dptr, dptr, dptr, uptr]),
+    "lifcal_write_raw_image_points_csv": (C.c_int, [C.c_char_p, C.c_uint64, C.c_uint32, _iptr, uptr, dptr, dptr, dptr, dptr, uptr]),
     "lifcal_write_protocol": (C.c_int, [C.c_char_p, C.POINTER(Protocol)]),
 }
 

@@ -110,9 +110,10 @@ int lifcal_write_extrinsic_orientations_txt(const char* path, uint32_t n_frames,
   return std::fclose(f) == 0 ? 0 : LIFCAL_BA_ERR_INVALID_ARG;
 }
 
-int lifcal_write_raw_image_points_csv(const char* path, uint64_t n_obs, const int32_t* frame_ids, const uint32_t* fr, const double* u,
+int lifcal_write_raw_image_points_csv(const char* path, uint64_t n_obs, uint32_t n_frames, const int32_t* frame_ids, const uint32_t* fr, const double* u,
                                       const double* v, const double* x_proj, const double* y_proj, const uint32_t* pt) {
   if (!path || (n_obs && (!frame_ids || !fr || !u || !v || !x_proj || !y_proj || !pt))) return LIFCAL_BA_ERR_INVALID_ARG;
+  for (uint64_t k = 0; k < n_obs; ++k) if (fr[k] >= n_frames) { g_last_error = "lifcal_write_raw_image_points_csv: frame index out of range"; return LIFCAL_BA_ERR_OUT_OF_RANGE; }
   for (uint64_t k = 1; k < n_obs; ++k) if (fr[k] < fr[k - 1]) { g_last_error = "lifcal_write_raw_image_points_csv: observations are not in frame order"; return LIFCAL_BA_ERR_INVALID_ARG; }
   FILE* f = std::fopen(path, "w");
   if (!f) return LIFCAL_BA_ERR_INVALID_ARG;

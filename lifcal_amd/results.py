@@ -55,7 +55,7 @@ def storeRawImagePointsCsv(dir_results: str, frame_ids, fr, u, v, x_proj, y_proj
     ids = np.ascontiguousarray(frame_ids, np.int32)
     fr = np.ascontiguousarray(fr, np.uint32); pt = np.ascontiguousarray(pt, np.uint32)
     arrs = [np.ascontiguousarray(a, np.float64) for a in (u, v, x_proj, y_proj)]
-    _ok(capi.load_library().lifcal_write_raw_image_points_csv(os.path.join(dir_results, "rawImagePoints.csv").encode(), len(fr), ids.ctypes.data_as(capi._iptr),
+    _ok(capi.load_library().lifcal_write_raw_image_points_csv(os.path.join(dir_results, "rawImagePoints.csv").encode(), len(fr), len(ids), ids.ctypes.data_as(capi._iptr),
                                                               capi.as_uptr(fr), *[capi.as_dptr(a) for a in arrs], capi.as_uptr(pt)), "storeRawImagePointsCsv")
 
 

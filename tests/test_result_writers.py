@@ -82,7 +82,9 @@ def test_raw_image_points_csv(tmp_path, built):
         assert line == "%d,%d,%f,%f,%f,%f,%d" % (ids[fr[k]], within[k], u[k], v[k], xp[k], yp[k], pt[k])
     assert len(lines) == 6
     with pytest.raises(LifcalError):
-        results.storeRawImagePointsCsv(str(tmp_path), ids, fr[::-1].copy(), u, v, xp, yp, pt)
+        results.storeRawImagePointsCsv(str(tmp_path), ids, fr[::-1].copy(), u, v, xp, yp, pt)      # not in frame order
+    with pytest.raises(LifcalError):
+        results.storeRawImagePointsCsv(str(tmp_path), ids[:3], fr, u, v, xp, yp, pt)               # frame index 3 of 3 frames
 
 
 def test_protocol(tmp_path, built):
