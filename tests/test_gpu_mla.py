@@ -152,3 +152,30 @@ def test_observations_feed_the_bundle_adjustment_layout():
     # central projection (:748-749), in double from the float results
     assert np.allclose((a.u - a.mcx) * np.float32(vd[a.src]) + a.mcx, np.float32(x[a.src]), atol=2e-3)
     g.close()
+
+
+def test_random_grids_and_points_stay_identical():
+    """120 random lens grids (diameter 5..45 px, any rotation, offsets, squeezed lattices, rotation on or off the grid) with
+    3000 random image points each, over the borders and across the whole virtual-depth range: every list bit for bit."""
+    from lifcal_amd.mla import MicroLensGrid
+    from oracle.mla import MicroLensGrid as OracleGrid
+    rng = np.random.default_rng(20241022)
+    n_obs = 0
+    for case in range(120):
+        kw = dict(width=int(rng.integers(48, 420)), height=int(rng.integers(48, 420)), lens_diameter=float(rng.uniform(5.0, 45.0)),
+                  lens_base_y=(0.5, float(rng.uniform(0.80, 0.92))), rotation=float(rng.uniform(-0.6, 0.6)) if case % 3 else float(rng.uniform(-0.01, 0.01)),
+                  offset=(float(rng.uniform(-25, 25)), float(rng.uniform(-25, 25))), rotation_on_grid=bool(case % 4))
+        g = MicroLensGrid(**kw); o = OracleGrid(**kw)
+        for a, b in zip(g.lenses() + g.web() + g.maps(), o.lenses() + o.web() + o.maps()):
+            assert np.array_equal(a, b), (case, kw)
+        scale = int(rng.integers(1, 4))
+        n = 3000
+        x = rng.uniform(-0.05 * g.width, 1.05 * g.width, n) / scale
+        y = rng.uniform(-0.05 * g.height, 1.05 * g.height, n) / scale
+        vd = rng.uniform(1.5, 21.0, n)
+        a = g.projectPointsToRawImage(x, y, vd, scale)
+        b = o.project_frame(x, y, vd, scale)
+        _same(a, b)
+        n_obs += len(a.u)
+        g.close()
+    assert n_obs > 500_000
