@@ -116,8 +116,8 @@ int dev_alloc(lifcal_ba_handle* h, T** p, size_t n) {
   h->bytes += n * sizeof(T);
   return 0;
 }
-template <class T>
-int dev_upload(lifcal_ba_handle* h, T** p, const std::vector<T>& v) {
+template <class T, class A>
+int dev_upload(lifcal_ba_handle* h, T** p, const std::vector<T, A>& v) {
   if (int rc = dev_alloc(h, p, v.size())) return rc;
   if (!v.empty()) HIP_TRY(hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
   return 0;
@@ -493,7 +493,9 @@ int lifcal_init_plenoptic(const lifcal_init_problem* p, int32_t device, lifcal_i
 int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size, lifcal_ba_plan_info* info,
                    uint32_t* obs_order, uint32_t* point_owner) {
   Plan pl;
-  if (int rc = build_plan(p, rank, world_size, &pl)) return rc;
+  // the same layout lifcal_ba_create builds by default (lanes in frame order for the wave-specialised sweep kernel)
+  const bool frame_order = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
+  if (int rc = build_plan(p, rank, world_size, &pl, true, 256, UINT32_MAX, frame_order)) return rc;
   if (info) {
     info->n_groups = pl.n_pairs; info->n_tiles = pl.n_tiles; info->n_lenses = pl.n_lenses; info->n_promoted = pl.Q;
     info->n_reduced = pl.n_red_canon; info->max_group_obs = pl.max_group_obs; info->n_chunks = pl.n_blocks; info->max_window_frames = pl.bw + 1;

@@ -16,18 +16,38 @@
 //     the reduced system so that the eliminated point blocks stay independent.
 // Pure host C++ (no HIP), so the CPU test-suite can exercise it through lifcal_ba_plan().
 #pragma once
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <numeric>
+#include <atomic>
+#include <new>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
 #include "../../include/lifcal_ba.h"
 
 namespace lifcal {
+
+// Storage for the large padded [k][lane] arrays: pages come zeroed from the OS (calloc) and value-initialisation is a no-op, so
+// a resize does not touch them; the first touch happens in the threads that fill the rows.
+template <class T>
+struct LazyZeroAlloc {
+  using value_type = T;
+  LazyZeroAlloc() = default;
+  template <class U> LazyZeroAlloc(const LazyZeroAlloc<U>&) {}
+  T* allocate(size_t n) { void* q = std::calloc(n ? n : 1, sizeof(T)); if (!q) throw std::bad_alloc(); return (T*)q; }
+  void deallocate(T* q, size_t) { std::free(q); }
+  template <class U> void construct(U*) noexcept {}
+  template <class U, class A0, class... A> void construct(U* q, A0&& a0, A&&... a) { ::new ((void*)q) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+  template <class U> bool operator==(const LazyZeroAlloc<U>&) const { return true; }
+  template <class U> bool operator!=(const LazyZeroAlloc<U>&) const { return false; }
+};
+template <class T> using ZeroVec = std::vector<T, LazyZeroAlloc<T>>;
 
 struct Plan {
   // problem sizes
@@ -82,7 +102,7 @@ struct Plan {
   std::vector<uint32_t> v2_slot;       // per (pass*256 + wave*64 + lane): cnt | lf<<8 | lp<<16 | rep<<24 ; 0 = idle
   std::vector<uint32_t> v2f_pt, v2f_fr, v2f_cnt;   // the same slots, flat (value-only kernels: cost, statistics)
   std::vector<uint32_t> v2_tile_row0;  // 4*n_passes+1
-  std::vector<double> v2_u, v2_v; std::vector<uint32_t> v2_lens, v2_src;
+  ZeroVec<double> v2_u, v2_v; ZeroVec<uint32_t> v2_lens; std::vector<uint32_t> v2_src;
   std::vector<uint32_t> special_owned; // owned points handled by the v1 kernels (promoted / constrained / oversized)
   uint32_t n_obs_v2 = 0;
   // lenses
@@ -111,8 +131,44 @@ inline int plan_validate(const lifcal_ba_problem* p) {
   return 0;
 }
 
+// The per-pass layout work (sorting a pass's lanes, gathering its observations into the [k][lane] rows) is independent
+// from pass to pass: a few host threads share it (LIFCAL_PLAN_THREADS overrides the default of min(8, cores)).
+template <class F>
+inline void plan_parallel_for(uint32_t n, uint32_t grain, F&& fn) {
+  unsigned hw = std::thread::hardware_concurrency();
+  unsigned T = std::min(8u, hw ? hw : 1u);
+  if (const char* e = getenv("LIFCAL_PLAN_THREADS")) T = (unsigned)std::max(1, atoi(e));
+  if (T <= 1 || n <= grain) { for (uint32_t i = 0; i < n; ++i) fn(i); return; }
+  std::atomic<uint32_t> next{0};
+  auto work = [&]() {
+    for (;;) {
+      const uint32_t b = next.fetch_add(grain);
+      if (b >= n) break;
+      for (uint32_t i = b; i < std::min(n, b + grain); ++i) fn(i);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned t = 1; t < T; ++t) pool.emplace_back(work);
+  work();
+  for (std::thread& t : pool) t.join();
+}
+
+// LIFCAL_PLAN_TIMING=1: wall time of each planner phase on stderr
+struct PlanClock {
+  bool on = getenv("LIFCAL_PLAN_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void lap(const char* what) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[plan] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+
 inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl, bool enable_v2 = true, uint32_t target_blocks = 256, uint32_t split_obs = UINT32_MAX, bool frame_order = false) {
+  PlanClock clk;
   if (int rc = plan_validate(p)) return rc;
+  clk.lap("validate");
   if (world < 1 || rank < 0 || rank >= world) return LIFCAL_BA_ERR_INVALID_ARG;
   Plan& L = *pl;
   L.F = p->n_frames; L.P = p->n_points; L.N = p->n_obs; L.M = p->n_constraints;
@@ -138,6 +194,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   L.bw = 0;
   for (uint32_t q = 0; q < L.P; ++q) if (cnt[q]) L.bw = std::max(L.bw, last[q] - first[q]);
 
+  clk.lap("per-point extents");
   // --- constraints / promotion ---
   L.promoted.assign(L.P, -1); L.promoted_ids.clear();
   L.c_i.clear(); L.c_j.clear(); L.c_dist.clear(); L.c_sigma.clear();
@@ -154,6 +211,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   L.n_red_int = 6 * L.F + L.NA;
   L.n_red_canon = LIFCAL_BA_MAX_CAMERA_PARAMETERS + 6 * L.F + 3 * L.Q;
 
+  clk.lap("constraints/promotion");
   // --- point order and ownership ---
   L.point_order.resize(L.P);
   std::iota(L.point_order.begin(), L.point_order.end(), 0u);
@@ -180,34 +238,72 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     for (int r = 0; r < world; ++r) if (lo[r] != UINT32_MAX) { L.rk_flo[r] = lo[r]; L.rk_nfr[r] = hi[r] - lo[r] + 1; }
   }
 
+  clk.lap("point order");
   // --- local observations sorted by (point order, frame) ---
   std::vector<uint32_t> order_rank(L.P, 0);
   for (uint32_t r = 0; r < L.P; ++r) order_rank[L.point_order[r]] = r;
-  L.obs_order.clear();
-  for (uint32_t i = 0; i < L.N; ++i) if (L.owner[p->pt[i]] == rank) L.obs_order.push_back(i);
-  std::stable_sort(L.obs_order.begin(), L.obs_order.end(), [&](uint32_t a, uint32_t b) {
-    const uint32_t ra = order_rank[p->pt[a]], rb = order_rank[p->pt[b]];
-    if (ra != rb) return ra < rb;
-    return p->fr[a] < p->fr[b];
-  });
+  {
+    // stable counting sort by the point's rank, then each point's short run by frame (stable: input order breaks ties)
+    std::vector<uint32_t> start(L.P + 1, 0);
+    for (uint32_t i = 0; i < L.N; ++i) if (L.owner[p->pt[i]] == rank) ++start[order_rank[p->pt[i]] + 1];
+    for (uint32_t r = 0; r < L.P; ++r) start[r + 1] += start[r];
+    L.obs_order.assign(start[L.P], 0);
+    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+    for (uint32_t i = 0; i < L.N; ++i) if (L.owner[p->pt[i]] == rank) L.obs_order[fill[order_rank[p->pt[i]]]++] = i;
+    for (uint32_t r = 0; r < L.P; ++r) {
+      uint32_t* b = L.obs_order.data() + start[r]; uint32_t* e = L.obs_order.data() + start[r + 1];
+      bool sorted = true;
+      for (uint32_t* q = b; q + 1 < e; ++q) if (p->fr[q[1]] < p->fr[q[0]]) { sorted = false; break; }
+      if (!sorted) std::stable_sort(b, e, [&](uint32_t a, uint32_t c) { return p->fr[a] < p->fr[c]; });
+    }
+  }
   L.n_obs_local = (uint32_t)L.obs_order.size();
 
+  clk.lap("obs sort");
   // --- lenses: exact-bit de-duplication of (mcx, mcy) over the local observations ---
   struct Key { uint64_t a, b; bool operator==(const Key& o) const { return a == o.a && b == o.b; } };
-  struct KeyHash { size_t operator()(const Key& k) const { return (size_t)(k.a * 0x9E3779B97F4A7C15ull ^ (k.b + 0x7F4A7C15ull + (k.a << 6))); } };
-  std::unordered_map<Key, uint32_t, KeyHash> lens_map;
-  lens_map.reserve(1 << 16);
+  struct KeyHash {   // the low bits index the table: finish with an avalanche step (doubles share most of their low mantissa bits)
+    size_t operator()(const Key& k) const {
+      uint64_t h = k.a * 0x9E3779B97F4A7C15ull ^ (k.b * 0xC2B2AE3D27D4EB4Full + (k.a >> 31));
+      h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+      return (size_t)h;
+    }
+  };
+  // open-addressing table (linear probing, load <= 1/2, doubles when full): ids in order of first appearance
   std::vector<uint32_t> obs_lens(L.n_obs_local);
   L.lens_xy.clear();
-  for (uint32_t s = 0; s < L.n_obs_local; ++s) {
-    const uint32_t i = L.obs_order[s];
-    Key k; std::memcpy(&k.a, &p->mcx[i], 8); std::memcpy(&k.b, &p->mcy[i], 8);
-    auto it = lens_map.find(k);
-    if (it == lens_map.end()) { it = lens_map.emplace(k, (uint32_t)(L.lens_xy.size() / 2)).first; L.lens_xy.push_back(p->mcx[i]); L.lens_xy.push_back(p->mcy[i]); }
-    obs_lens[s] = it->second;
+  {
+    size_t cap = 1 << 15;
+    std::vector<uint32_t> table(cap, UINT32_MAX);
+    KeyHash hash;
+    auto key_of = [&](uint32_t id) { Key k; std::memcpy(&k.a, &L.lens_xy[2 * (size_t)id], 8); std::memcpy(&k.b, &L.lens_xy[2 * (size_t)id + 1], 8); return k; };
+    auto grow = [&]() {
+      cap *= 2;
+      table.assign(cap, UINT32_MAX);
+      for (uint32_t id = 0; id < (uint32_t)(L.lens_xy.size() / 2); ++id) {
+        size_t at = hash(key_of(id)) & (cap - 1);
+        while (table[at] != UINT32_MAX) at = (at + 1) & (cap - 1);
+        table[at] = id;
+      }
+    };
+    for (uint32_t s = 0; s < L.n_obs_local; ++s) {
+      const uint32_t i = L.obs_order[s];
+      Key k; std::memcpy(&k.a, &p->mcx[i], 8); std::memcpy(&k.b, &p->mcy[i], 8);
+      size_t at = hash(k) & (cap - 1);
+      uint32_t id;
+      while ((id = table[at]) != UINT32_MAX && !(key_of(id) == k)) at = (at + 1) & (cap - 1);
+      if (id == UINT32_MAX) {
+        id = (uint32_t)(L.lens_xy.size() / 2);
+        table[at] = id;
+        L.lens_xy.push_back(p->mcx[i]); L.lens_xy.push_back(p->mcy[i]);
+        if ((size_t)(id + 1) * 2 > cap) grow();
+      }
+      obs_lens[s] = id;
+    }
   }
   L.n_lenses = (uint32_t)(L.lens_xy.size() / 2);
 
+  clk.lap("lens dedup");
   // --- groups (runs of equal (point, frame)), gid numbering ---
   struct Group { uint32_t pt, fr, s0, n; };
   std::vector<Group> groups;
@@ -229,6 +325,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   L.max_group_obs = 0;
   for (const Group& G : groups) L.max_group_obs = std::max(L.max_group_obs, G.n);
 
+  clk.lap("groups");
   // --- classify points: regular (v2) or special (v1 fallback) ---
   std::vector<uint8_t> special(L.P, 0);
   if (L.use_constraints) for (uint32_t c = 0; c < L.M; ++c) { special[L.c_i[c]] = 1; special[L.c_j[c]] = 1; }
@@ -239,6 +336,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   }
   for (const Group& G : groups) if (G.n > 255) special[G.pt] = 1;   // the v2 slot word keeps the group size in 8 bits
 
+  clk.lap("classify");
   // --- v2 blocks: contiguous ranges of regular points with ~reg_obs/target observations each, window <= NF_MAX ---
   std::vector<uint32_t> reg;                 // regular points in point order
   std::vector<size_t> blk_begin;             // block b = reg[blk_begin[b] .. blk_begin[b+1])
@@ -271,6 +369,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     return std::max(1u, std::min<uint32_t>(Plan::NP_MAX, ((Plan::ZD_DOUBLES / (ncolp + 2)) & ~7u) / 3));
   };
 
+  clk.lap("v2 blocks");
   // --- lanes: a (point, frame) group of a regular point with more than T observations is cut into near-equal parts, one
   // lane each.  A wave walks max(lane size) observation steps, so this trades a few more lanes (and their block emission)
   // for fewer idle steps; every consumer (LDS accumulation, W staging, back-substitution) is linear in the per-lane
@@ -284,7 +383,8 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     // cycles per observation step of a pass, per pass, per lane (LIFCAL_PLAN_COST="step,pass,lane" overrides: tuning aid)
     double C_STEP = 4700.0, C_PASS = 21500.0, C_LANE = 65.0;
     if (const char* e = getenv("LIFCAL_PLAN_COST")) { double a, b2, c2; if (sscanf(e, "%lf,%lf,%lf", &a, &b2, &c2) == 3) { C_STEP = a; C_PASS = b2; C_LANE = c2; } }
-    for (size_t b = 0; b + 1 < blk_begin.size(); ++b) {
+    // blocks are independent (each writes split_of / pass_break of its own points only)
+    plan_parallel_for(blk_begin.empty() ? 0u : (uint32_t)(blk_begin.size() - 1), 4, [&](uint32_t b) {
       const uint32_t np_cap = block_np_cap(b);
       const size_t i0 = blk_begin[b], n = blk_begin[b + 1] - i0;
       uint32_t nmax = 0;
@@ -326,7 +426,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
         for (size_t k = i; k < nxt[i]; ++k) split_of[reg[i0 + k]] = Ts[pick[i]];
         if (i > 0) pass_break[reg[i0 + i]] = 1;
       }
-    }
+    });
     std::vector<Group> cut;
     cut.reserve(groups.size() * 2);
     for (const Group& G : groups) {
@@ -349,6 +449,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     }
   }
 
+  clk.lap("lanes/passes");
   // --- v1 tiles from the special points' groups ---
   std::vector<uint32_t> g1;
   for (uint32_t g = 0; g < L.n_groups; ++g) if (special[groups[g].pt]) g1.push_back(g);
@@ -377,6 +478,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     }
   }
 
+  clk.lap("v1 tiles");
   // --- v2 passes inside each block ---
   L.v2_points.clear(); L.v2_ptinfo.clear(); L.blk_pass0.assign(1, 0);
   L.pass_pt0.clear(); L.pass_np.clear(); L.pass_gid0.clear(); L.pass_ng.clear();
@@ -396,6 +498,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     }
     L.blk_pass0.push_back((uint32_t)L.pass_pt0.size());
   }
+  clk.lap("v2: pass ranges");
   L.n_blocks = (uint32_t)L.blk_flo.size(); L.n_passes = (uint32_t)L.pass_pt0.size();
   L.v2_passpt.assign((size_t)L.n_passes * Plan::NP_MAX, 0);
   for (uint32_t ps = 0; ps < L.n_passes; ++ps)
@@ -413,14 +516,16 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
           const uint32_t q = L.v2_points[L.pass_pt0[ps] + k];
           for (uint32_t g = L.pt_slot0[q]; g < L.pt_slot0[q] + L.pt_nslots[q]; ++g) pass_groups[ps].push_back(g);
         }
+  clk.lap("v2: pass groups");
     // lane slot of the k-th group of a pass.  Point order (k_sweep2): group k -> wave k % 4, lane k / 4, the lanes of a
     // point sit side by side and the frame accumulators are replicated.  Frame order (k_sweep3): the pass's lanes are sorted
     // by frame and cut into four tiles of 64, so the lanes of ONE frame sit side by side and their frame-level blocks are
     // summed with DPP before a single lane adds them to LDS.
     struct LaneOf { uint32_t gid, lp; };
     std::vector<std::vector<LaneOf>> lanes(L.n_passes);
-    for (uint32_t ps = 0; ps < L.n_passes; ++ps) {
+    plan_parallel_for(L.n_passes, 16, [&](uint32_t ps) {
       uint32_t lp = 0, left = 0;
+      lanes[ps].reserve(pass_groups[ps].size());
       for (uint32_t k = 0; k < pass_groups[ps].size(); ++k) {
         const Group& G = groups[pass_groups[ps][k]];
         if (k == 0) { lp = 0; left = L.pt_nslots[G.pt]; }
@@ -430,7 +535,8 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
       }
       if (frame_order)
         std::stable_sort(lanes[ps].begin(), lanes[ps].end(), [&](const LaneOf& x, const LaneOf& y) { return groups[x.gid].fr < groups[y.gid].fr; });
-    }
+    });
+  clk.lap("v2: lanes+sort");
     auto slot_of = [&](uint32_t k, uint32_t& w, uint32_t& l) { if (frame_order) { w = k / 64; l = k % 64; } else { w = k % 4; l = k / 4; } };
     for (uint32_t ps = 0; ps < L.n_passes; ++ps) {
       uint32_t kmax[4] = {0, 0, 0, 0};
@@ -438,10 +544,15 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
       for (uint32_t w = 0; w < 4; ++w) L.v2_tile_row0[(size_t)ps * 4 + w + 1] = L.v2_tile_row0[(size_t)ps * 4 + w] + kmax[w];
     }
     const size_t rows = L.v2_tile_row0[(size_t)L.n_passes * 4];
-    L.v2_u.assign(rows * 64, 0.0); L.v2_v.assign(rows * 64, 0.0); L.v2_lens.assign(rows * 64, 0); L.v2_src.assign(rows * 64, UINT32_MAX);
+    L.v2_u = ZeroVec<double>(); L.v2_v = ZeroVec<double>(); L.v2_lens = ZeroVec<uint32_t>();   // fresh storage: zero pages, untouched
+    L.v2_u.resize(rows * 64); L.v2_v.resize(rows * 64); L.v2_lens.resize(rows * 64); L.v2_src.assign(rows * 64, UINT32_MAX);
     L.v2_gidx.assign((size_t)L.n_passes * 256, 0);
-    for (uint32_t b = 0; b < L.n_blocks; ++b)
-      for (uint32_t ps = L.blk_pass0[b]; ps < L.blk_pass0[b + 1]; ++ps) {
+  clk.lap("v2: rows+alloc");
+    std::vector<uint32_t> pass_block(L.n_passes, 0);
+    for (uint32_t b = 0; b < L.n_blocks; ++b) for (uint32_t ps = L.blk_pass0[b]; ps < L.blk_pass0[b + 1]; ++ps) pass_block[ps] = b;
+    plan_parallel_for(L.n_passes, 8, [&](uint32_t ps) {
+      {
+        const uint32_t b = pass_block[ps];
         // replica = occurrence rank of the lane's frame inside its wave (point order only: k_sweep2's replicated accumulators)
         std::vector<uint32_t> occ(4 * (Plan::NF_MAX + 1), 0);
         for (uint32_t k = 0; k < lanes[ps].size(); ++k) {
@@ -463,8 +574,10 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
         // the pass's gids must be one contiguous run for the W staging (true unless a special point sits inside)
         L.pass_gid0[ps] = pass_groups[ps].empty() ? 0 : pass_groups[ps][0];
       }
+    });
   }
 
+  clk.lap("v2 passes");
   // --- constraints owned by this rank; CSR of partner columns per eliminated point ---
   L.my_constraints.clear();
   L.pt_cons0.assign(L.P + 1, 0); L.pt_cons_list.clear();
@@ -478,9 +591,18 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     // a point that is only constrained (never observed) still needs an owner
     for (uint32_t c = 0; c < L.M; ++c) if (L.owner[L.c_i[c]] < 0) { L.owner[L.c_i[c]] = 0; if (rank == 0) L.owned_points.push_back(L.c_i[c]); }
   }
+  clk.lap("constraints csr");
   L.pt_special = special;
   L.special_owned.clear();
   for (uint32_t q : L.owned_points) if (special[q] || L.pt_nslots[q] == 0) { L.special_owned.push_back(q); L.pt_special[q] = 1; }
+  if (getenv("LIFCAL_PLAN_HASH")) {   // fingerprint of the layout, to compare planner versions
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* q, size_t bytes) { const unsigned char* c = (const unsigned char*)q; for (size_t k = 0; k < bytes; ++k) { h ^= c[k]; h *= 1099511628211ull; } };
+    auto mixv = [&](const auto& v) { if (!v.empty()) mix(v.data(), v.size() * sizeof(v[0])); };
+    mixv(L.obs_order); mixv(L.lens_xy); mixv(L.ell_u); mixv(L.ell_v); mixv(L.ell_lens); mixv(L.ell_src); mixv(L.v2_u); mixv(L.v2_v); mixv(L.v2_lens); mixv(L.v2_src);
+    mixv(L.v2_slot); mixv(L.v2f_pt); mixv(L.v2f_fr); mixv(L.v2f_cnt); mixv(L.v2_gidx); mixv(L.v2_tile_row0); mixv(L.v2_passpt); mixv(L.tile_row0); mixv(L.pt_slot0); mixv(L.pt_nslots);
+    std::fprintf(stderr, "[plan] hash %016llx\n", (unsigned long long)h);
+  }
   return 0;
 }
 
