@@ -529,8 +529,10 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   const uint32_t split_obs = getenv("LIFCAL_GROUP_SPLIT") ? (uint32_t)std::max(0, atoi(getenv("LIFCAL_GROUP_SPLIT"))) : UINT32_MAX;
   // the wave-specialised kernel wants the lanes of a pass sorted by frame, k_sweep2 (LIFCAL_SWEEP_KERNEL=2) by point
   h->use_sweep3 = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
+  PlanClock cclk;
   int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs, h->use_sweep3);
   if (rc) { delete h; return rc; }
+  cclk.lap("create: plan");
   h->prob = *p;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || opt.device >= ndev) {
@@ -545,6 +547,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   auto fail = [&](int code) { lifcal_ba_destroy(h); return code; };
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
+  cclk.lap("create: device, stream");
 
   const Plan& L = h->plan;
   Dev& d = h->d;
@@ -656,8 +659,10 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   }
 #undef A
 #undef U
+  cclk.lap("create: alloc + upload");
   if (hipHostMalloc((void**)&h->h_scal, (SCAL_N + 2 * ST_N + 16) * sizeof(double)) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
   if (int rc2 = upload_parameters(h)) return fail(rc2);
+  cclk.lap("create: parameters");
   *out = h;
   return 0;
 }
