@@ -61,7 +61,8 @@ def _worker(rank, world, port, out_dir, spec_kw, mode):
     summ = ba.performBundleAdjustment()
     st = ba.calcReprojectionError()
     info = ba.info()
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cam=pa.cam, views=pa.views, pts=pa.pts, cost0=sw.cost,
+    xp, yp = ba.projectObservations()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cam=pa.cam, views=pa.views, pts=pa.pts, cost0=sw.cost, xp=xp, yp=yp,
              S=sw.S if rank == 0 else np.zeros(1), rhs=sw.rhs if rank == 0 else np.zeros(1),
              gather_calls=calls["gather"], gather_doubles=calls["gather_doubles"], n_red=info.n_reduced,
              it=summ.iterations, term=summ.termination, final=summ.final_cost, n_local=info.n_obs_local,
@@ -106,8 +107,14 @@ def test_ranks_match_the_single_process_oracle(built, tmp_path, spec_kw, mode, w
         assert np.allclose(r["pts"], pb.pts, rtol=0, atol=1e-6 * (1 + np.abs(pb.pts).max()))
         assert np.allclose(r["views"], pb.views, rtol=0, atol=1e-6 * (1 + np.abs(pb.views).max()))
     assert np.array_equal(r0["pts"], r1["pts"]) and np.array_equal(r0["cam"], r1["cam"])
-    stt = oracle.reproj_stats(capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, r0["cam"], r0["views"], r0["pts"], sc.spx, sc.scale, sc.config))
+    stt, err = oracle.reproj_stats(capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, r0["cam"], r0["views"], r0["pts"], sc.spx, sc.scale, sc.config), want_errors=True)
     assert abs(float(r0["stats"][0]) - stt.std_x) < 1e-9 and int(r0["stats"][2]) == sc.n_obs
+    # lifcal_ba_project_observations: a rank fills the observations of the points it owns (NaN elsewhere); together the ranks
+    # cover every observation exactly once, with the projection of the final parameters
+    xs = np.stack([np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))["xp"] for r in range(world)])
+    filled = np.isfinite(xs)
+    assert np.all(filled.sum(0) == 1) and [int(f.sum()) for f in filled] == n_local
+    assert np.max(np.abs(np.nansum(xs, 0) - (sc.u + err[:, 0]))) < 1e-8
 
 
 @pytest.mark.parametrize("k,world", [(11, 2), (22, 3), (26, 4), (37, 2), (41, 3)])   # (multiples of 5 are the big scenes of the family: too slow for the oracle here)
