@@ -148,7 +148,9 @@ inline void plan_parallel_for(uint32_t n, uint32_t grain, F&& fn) {
     }
   };
   std::vector<std::thread> pool;
-  for (unsigned t = 1; t < T; ++t) pool.emplace_back(work);
+  for (unsigned t = 1; t < T; ++t) {
+    try { pool.emplace_back(work); } catch (...) { break; }   // no more threads to be had: the ones running share the work
+  }
   work();
   for (std::thread& t : pool) t.join();
 }
