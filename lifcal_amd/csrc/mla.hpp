@@ -302,6 +302,9 @@ struct lifcal_mla_handle {
   mla::Dev dev{};
   int32_t device = 0;
   std::vector<void*> allocs;
+  // scratch of lifcal_mla_project, kept between calls and grown on demand (hipFree costs about 2 ms per call otherwise):
+  // the k-th request of a call reuses the k-th buffer
+  std::vector<std::pair<void*, size_t>> scratch;
 };
 
 namespace mla {
@@ -386,7 +389,11 @@ int lifcal_mla_create(const lifcal_mla_params* p, int32_t device, lifcal_mla_han
 
 void lifcal_mla_destroy(lifcal_mla_handle* h) {
   if (!h) return;
-  if (!h->allocs.empty()) { (void)hipSetDevice(h->device); for (void* q : h->allocs) (void)hipFree(q); }
+  if (!h->allocs.empty() || !h->scratch.empty()) {
+    (void)hipSetDevice(h->device);
+    for (void* q : h->allocs) (void)hipFree(q);
+    for (auto& sl : h->scratch) if (sl.first) (void)hipFree(sl.first);
+  }
   delete h;
 }
 
@@ -435,14 +442,29 @@ int lifcal_mla_project(lifcal_mla_handle* h, int32_t depth_to_raw_im_scale, cons
   obs->n_obs = 0;
   if (pts->n == 0) return 0;
   HIP_TRY(hipSetDevice(h->device));
-  std::vector<void*> tmp;
-  auto release = [&]() { for (void* q : tmp) (void)hipFree(q); };
-  auto dev_alloc = [&](void** q, size_t bytes) -> hipError_t { hipError_t e = hipMalloc(q, bytes ? bytes : 8); if (e == hipSuccess) tmp.push_back(*q); return e; };
+  size_t next_scratch = 0;
+  auto release = [&]() {};   // buffers stay with the handle
+  auto dev_alloc = [&](void** q, size_t bytes) -> hipError_t {
+    if (bytes == 0) bytes = 8;
+    if (next_scratch == h->scratch.size()) h->scratch.push_back({nullptr, 0});
+    std::pair<void*, size_t>& slot = h->scratch[next_scratch++];
+    if (slot.second < bytes) {
+      if (slot.first) (void)hipFree(slot.first);
+      slot = {nullptr, 0};
+      const size_t want = bytes + bytes / 4;   // some slack: the next call is likely to be of similar size
+      hipError_t e = hipMalloc(&slot.first, want);
+      if (e != hipSuccess) { slot.first = nullptr; *q = nullptr; return e; }
+      slot.second = want;
+    }
+    *q = slot.first;
+    return hipSuccess;
+  };
   auto up = [&](const void** q, const void* src, size_t bytes) -> hipError_t {
     if (!src) { *q = nullptr; return hipSuccess; }
     void* w = nullptr; hipError_t e = dev_alloc(&w, bytes); *q = w;
     return e == hipSuccess ? hipMemcpy(w, src, bytes, hipMemcpyHostToDevice) : e;
   };
+  lifcal::PlanClock clk;
   mla::ProjectArgs a{};
   a.n = pts->n; a.scale = depth_to_raw_im_scale;
   const uint64_t n = pts->n;
@@ -455,6 +477,7 @@ int lifcal_mla_project(lifcal_mla_handle* h, int32_t depth_to_raw_im_scale, cons
   if (e == hipSuccess) e = dev_alloc((void**)&counts, (n + 1) * 8);
   if (e == hipSuccess) e = dev_alloc((void**)&offsets, (n + 1) * 8);
   if (e == hipSuccess) e = hipMemset(counts, 0, (n + 1) * 8);   // entry n stays 0: the scan's last output is the total
+  clk.lap("project: upload");
   uint64_t total = 0;
   const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 16);
   if (e == hipSuccess) {
@@ -469,6 +492,7 @@ int lifcal_mla_project(lifcal_mla_handle* h, int32_t depth_to_raw_im_scale, cons
     if (e == hipSuccess) e = hipcub::DeviceScan::ExclusiveSum(scratch, scratch_bytes, counts, offsets, (int)(n + 1));
     if (e == hipSuccess) e = hipMemcpy(&total, offsets + n, 8, hipMemcpyDeviceToHost);
   }
+  clk.lap("project: count + scan");
   if (e != hipSuccess) { release(); g_last_error = std::string("lifcal_mla_project: ") + hipGetErrorString(e); return LIFCAL_BA_ERR_HIP; }
   obs->n_obs = total;
   if (total > obs->capacity) { release(); return LIFCAL_MLA_MORE; }
@@ -481,10 +505,13 @@ int lifcal_mla_project(lifcal_mla_handle* h, int32_t depth_to_raw_im_scale, cons
   if (e == hipSuccess && obs->src) e = dev_alloc((void**)&a.src, total * 4);
   if (e == hipSuccess && obs->fr) e = dev_alloc((void**)&a.ofr, total * 4);
   if (e == hipSuccess && obs->pt) e = dev_alloc((void**)&a.opt, total * 4);
+  clk.lap("project: output alloc");
   if (e == hipSuccess) {
     hipLaunchKernelGGL(mla::k_mla_project<true>, dim3(grid), dim3(256), 0, 0, h->dev, a);
     e = hipGetLastError();
   }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  clk.lap("project: fill");
   if (e == hipSuccess) e = hipMemcpy(obs->u, a.u, total * 8, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(obs->v, a.v, total * 8, hipMemcpyDeviceToHost);
   if (e == hipSuccess) e = hipMemcpy(obs->mcx, a.mcx, total * 8, hipMemcpyDeviceToHost);
@@ -492,7 +519,9 @@ int lifcal_mla_project(lifcal_mla_handle* h, int32_t depth_to_raw_im_scale, cons
   if (e == hipSuccess && obs->src) e = hipMemcpy(obs->src, a.src, total * 4, hipMemcpyDeviceToHost);
   if (e == hipSuccess && obs->fr) e = hipMemcpy(obs->fr, a.ofr, total * 4, hipMemcpyDeviceToHost);
   if (e == hipSuccess && obs->pt) e = hipMemcpy(obs->pt, a.opt, total * 4, hipMemcpyDeviceToHost);
+  clk.lap("project: download");
   release();
+  clk.lap("project: free");
   if (e != hipSuccess) { g_last_error = std::string("lifcal_mla_project: ") + hipGetErrorString(e); return LIFCAL_BA_ERR_HIP; }
   return 0;
 }
