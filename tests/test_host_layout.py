@@ -148,3 +148,27 @@ def test_empty_and_degenerate_problems(built):
     one = capi.ProblemArrays(sc.u[:1], sc.v[:1], sc.mcx[:1], sc.mcy[:1], sc.pt[:1], sc.fr[:1], sc.cam0, sc.views0, sc.pts0, sc.spx, sc.scale, sc.config)
     info, order, owner = plan(one)
     assert info.n_groups == 1 and info.n_tiles in (1, 4) and info.max_group_obs == 1
+
+
+def test_planner_threads_do_not_change_the_layout(built, capfd, monkeypatch):
+    """the per-block / per-pass planner work is shared by host threads: every array of the layout (fingerprint printed under
+    LIFCAL_PLAN_HASH) is the same with one thread and with eight, for both lane orders"""
+    import re
+    import lifcal_amd
+    from lifcal_amd import scene
+    sc = scene.make_scene(scene.SceneSpec(40, 2500, 8, 0xF06, 4242, outlier_fraction=0.02))
+    pa = capi.ProblemArrays.from_scene(sc)
+    monkeypatch.setenv("LIFCAL_PLAN_HASH", "1")
+    hashes = {}
+    for kernel in ("3", "2"):
+        monkeypatch.setenv("LIFCAL_SWEEP_KERNEL", kernel)
+        for threads in ("1", "8", "3"):
+            monkeypatch.setenv("LIFCAL_PLAN_THREADS", threads)
+            capfd.readouterr()
+            info, order, owner = lifcal_amd.plan(pa)
+            err = capfd.readouterr().err
+            m = re.search(r"\[plan\] hash ([0-9a-f]{16})", err)
+            assert m, err
+            hashes[(kernel, threads)] = (m.group(1), info.n_groups, info.n_chunks)
+        assert hashes[(kernel, "1")] == hashes[(kernel, "8")] == hashes[(kernel, "3")]
+    assert hashes[("3", "1")][0] != hashes[("2", "1")][0]          # the two kernels want different lane orders
