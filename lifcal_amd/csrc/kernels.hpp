@@ -775,7 +775,8 @@ __global__ __launch_bounds__(1024) void k_band_backsolve(Dev d) {
   double* x = d.delta_red;
   const double* y = d.Sarrow + (size_t)NA * ld;
   const double* Aa = d.Sarrow + 6 * F;
-  __shared__ double acc6[6];
+  __shared__ double part6[16][6];
+  const uint32_t wv = tid >> 6, nwv = (nt + 63) >> 6;
   for (uint32_t k = tid; k < d.n_red; k += nt) x[k] = y[k];
   __syncthreads();
   // arrow part (dense, lower factor Aa): x_a = (y_a - sum_{b>a} L[b][a] x_b) / L[a][a]
@@ -788,23 +789,25 @@ __global__ __launch_bounds__(1024) void k_band_backsolve(Dev d) {
   }
   // pose blocks, last to first: x_j = L_jj^-T (y_j - sum_{i>j} L_ij^T x_i - sum_a L_aj^T x_a)
   for (int j = (int)F - 1; j >= 0; --j) {
-    if (tid < 6) acc6[tid] = 0.0;
-    __syncthreads();
     const uint32_t nbel = min(bw, F - 1 - (uint32_t)j);
     const uint32_t nrows = 6 * nbel + NA;
-    // each thread handles one (row, k) product chain: 6 partial sums via LDS atomics on a tiny array
+    // each thread sums its rows, then a fixed-order wave / workgroup reduction: the solution is replicated across ranks and
+    // must come out as the same bits everywhere (no atomics)
+    double acc[6] = {0, 0, 0, 0, 0, 0};
     for (uint32_t r = tid; r < nrows; r += nt) {
       const double* src; double xv;
       if (r < 6 * nbel) { const uint32_t i = (uint32_t)j + 1 + r / 6; src = d.Sband + ((size_t)i * (bw + 1) + (i - j)) * 36 + (r % 6) * 6; xv = x[6 * i + r % 6]; }
       else { const uint32_t a = r - 6 * nbel; src = d.Sarrow + (size_t)a * ld + 6 * j; xv = x[6 * F + a]; }
 #pragma unroll
-      for (int k = 0; k < 6; ++k) atomicAdd(&acc6[k], src[k] * xv);
+      for (int k = 0; k < 6; ++k) acc[k] += src[k] * xv;
     }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { acc[k] = wave_sum(acc[k]); if ((tid & 63u) == 0) part6[wv][k] = acc[k]; }
     __syncthreads();
     if (tid == 0) {
       const double* Li = d.Linv + (size_t)j * 36;
       double t6[6], o[6];
-      for (int k = 0; k < 6; ++k) t6[k] = x[6 * j + k] - acc6[k];
+      for (int k = 0; k < 6; ++k) { double sum = 0.0; for (uint32_t w = 0; w < nwv; ++w) sum += part6[w][k]; t6[k] = x[6 * j + k] - sum; }
       for (int c = 0; c < 6; ++c) { double s = 0.0; for (int k = c; k < 6; ++k) s += Li[k * 6 + c] * t6[k]; o[c] = s; }  // L^-T t
       for (int k = 0; k < 6; ++k) x[6 * j + k] = o[k];
     }
@@ -817,10 +820,7 @@ __global__ __launch_bounds__(1024) void k_band_backsolve(Dev d) {
 // ---------------------------------------------------------------------------------------------
 // camera + poses + promoted points: candidate = Plus(x, delta) with box projection (ceres ParameterBlock::Plus)
 __global__ void k_update_reduced(Dev d, double* partial) {
-  __shared__ double red[4];
-  if (threadIdx.x < 4) red[threadIdx.x] = 0.0;
-  if (threadIdx.x < 8) partial[threadIdx.x] = 0.0;   // scalars of the candidate step (k_backsub / k_cost accumulate into them next)
-  __syncthreads();
+  __shared__ double red[4][4];
   const uint32_t F6 = 6 * d.F, camcol = F6 + 3 * d.Q;
   double gtd = 0.0, ddd = 0.0, st2 = 0.0, x2 = 0.0;
   for (uint32_t t = threadIdx.x; t < d.n_red; t += blockDim.x) {
@@ -830,10 +830,7 @@ __global__ void k_update_reduced(Dev d, double* partial) {
       const double xo = d.views[t], xn = xo + dl;
       d.views_c[t] = xn;
       if (d.use_poses && d.frame_live[t / 6]) { st2 += (xn - xo) * (xn - xo); x2 += xo * xo; }
-    } else if (t < camcol) {
-      const uint32_t q = (t - F6) / 3, k = (t - F6) % 3;
-      (void)q; (void)k;  // promoted points are written by k_backsub (it knows the point id)
-    }
+    }   // promoted points are written by k_backsub (it knows the point id)
   }
   for (uint32_t j = threadIdx.x; j < LIFCAL_BA_MAX_CAMERA_PARAMETERS; j += blockDim.x) {
     const double xo = d.cam[j];
@@ -844,9 +841,18 @@ __global__ void k_update_reduced(Dev d, double* partial) {
     d.cam_c[j] = xn;
     st2 += (xn - xo) * (xn - xo); x2 += xo * xo;
   }
-  atomicAdd(&red[0], gtd); atomicAdd(&red[1], ddd); atomicAdd(&red[2], st2); atomicAdd(&red[3], x2);
+  // fixed-order reduction (no atomics: the sums must not depend on scheduling).  The scalars of the reduced part are
+  // the same on every rank up to nothing at all, but they steer the host's accept / reject / terminate branches, which
+  // contain collectives: only rank 0 contributes them to the all-reduced buffer, so every rank decides on the same bits.
+  gtd = wave_sum(gtd); ddd = wave_sum(ddd); st2 = wave_sum(st2); x2 = wave_sum(x2);
+  const uint32_t wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63u) == 0) { red[wv][0] = gtd; red[wv][1] = ddd; red[wv][2] = st2; red[wv][3] = x2; }
   __syncthreads();
-  if (threadIdx.x == 0) { d.step[ST_GTD] += red[0]; d.step[ST_DDD] += red[1]; d.step[ST_STEP2] += red[2]; d.step[ST_X2] += red[3]; }
+  if (threadIdx.x < 8) {   // scalars of the candidate step (k_backsub / k_cost accumulate into them next)
+    double v = 0.0;
+    if (threadIdx.x < 4 && d.rank == 0) v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
+    partial[threadIdx.x] = v;
+  }
 }
 
 // points: delta_P = -U^-1 (g_p + W_p delta_B) for eliminated points, reduced solution for promoted ones
@@ -926,8 +932,10 @@ __global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by th
 }
 
 // candidate = Plus(x, t * delta) for an arbitrary step length t (ceres ParameterBlock::Plus incl. box projection), from
-// the stored reduced solution and point step; out[0] += |x - candidate|^2, out[1] += |x|^2 over this rank's share
-__global__ void k_apply_step(Dev d, double t, double* out_local, double* out_points) {
+// the stored reduced solution and point step; out[0] += |x - candidate|^2, out[1] += |x|^2 over this rank's share of the
+// points; the (replicated) camera + pose part is contributed by rank 0 only, so that the all-reduced sums are the same bits
+// on every rank (they steer host branches that contain collectives)
+__global__ void k_apply_step(Dev d, double t, double* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t F6 = 6 * d.F, camcol = F6 + 3 * d.Q;
   double st2r = 0.0, x2r = 0.0, st2p = 0.0, x2p = 0.0;
@@ -962,21 +970,42 @@ __global__ void k_apply_step(Dev d, double t, double* out_local, double* out_poi
       }
     }
   }
-  st2r = wave_sum(st2r); x2r = wave_sum(x2r); st2p = wave_sum(st2p); x2p = wave_sum(x2p);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(out_local + 0, st2r); atomicAdd(out_local + 1, x2r); atomicAdd(out_points + 0, st2p); atomicAdd(out_points + 1, x2p); }
+  if (d.rank == 0) { st2p += st2r; x2p += x2r; }
+  st2p = wave_sum(st2p); x2p = wave_sum(x2p);
+  if ((threadIdx.x & 63) == 0 && (st2p != 0.0 || x2p != 0.0)) { atomicAdd(out + 0, st2p); atomicAdd(out + 1, x2p); }
 }
 
-// directional derivative grad(x_trial) . delta after a sweep at the trial point: reduced part (replicated) and point part
-__global__ void k_dirderiv(Dev d, double* out_local, double* out_points) {
+// directional derivative grad(x_trial) . delta after a sweep at the trial point: point part of this rank (+ the replicated
+// reduced part on rank 0 only, see k_apply_step)
+__global__ void k_dirderiv(Dev d, double* out) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  double dr = 0.0, dp = 0.0;
-  if (i < d.n_red) dr = d.gB[i] * d.delta_red[i];
+  double dp = 0.0;
+  if (d.rank == 0 && i < d.n_red) dp = d.gB[i] * d.delta_red[i];
   if (d.use_points && i < d.n_owned) {
     const uint32_t p = d.owned[i];
     if (d.promoted[p] < 0) { const double* g = d.ptacc + (size_t)p * 36 + 6; for (int k = 0; k < 3; ++k) dp += g[k] * d.dP[3 * (size_t)p + k]; }
   }
-  dr = wave_sum(dr); dp = wave_sum(dp);
-  if ((threadIdx.x & 63) == 0) { atomicAdd(out_local, dr); atomicAdd(out_points, dp); }
+  dp = wave_sum(dp);
+  if ((threadIdx.x & 63) == 0 && dp != 0.0) atomicAdd(out, dp);
+}
+
+// largest |component| of the step (line search: ceres' minimum-step test runs on the whole direction vector).  Maxima
+// travel as bit patterns in one slot per rank, summed by the all-reduce (the other ranks' slots hold 0): slot[rank] = this
+// rank's points, slot[64] = the replicated camera + pose part, written by rank 0 alone
+__global__ void k_dir_max(Dev d, unsigned long long* slots) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  double mr = 0.0, mp = 0.0;
+  if (d.rank == 0 && i < d.n_red) mr = fabs(d.delta_red[i]);
+  if (d.use_points && i < d.n_owned) {
+    const uint32_t p = d.owned[i];
+    if (d.promoted[p] < 0) for (int k = 0; k < 3; ++k) mp = fmax(mp, fabs(d.dP[3 * (size_t)p + k]));
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { mr = fmax(mr, __shfl_xor(mr, m, 64)); mp = fmax(mp, __shfl_xor(mp, m, 64)); }
+  if ((threadIdx.x & 63) == 0) {
+    if (mr > 0.0) atomicMax(slots + 64, (unsigned long long)__double_as_longlong(mr));
+    if (mp > 0.0) atomicMax(slots + d.rank, (unsigned long long)__double_as_longlong(mp));
+  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -85,6 +85,7 @@ struct lifcal_ba_handle {
   double* partial = nullptr;     // 4 doubles + 1 cand cost (all-reduced)
   double* hdiag_tmp = nullptr;
   double* stats_buf = nullptr;   // 4 sums + 2 max bit patterns
+  double* stats_slots = nullptr; // multi-rank: 4 sums + one (max x, max y) pair per rank
   double* lens_xy = nullptr;
   double* pts_gather = nullptr;
   CamConsts* camc_stats = nullptr;
@@ -97,7 +98,9 @@ struct lifcal_ba_handle {
   void* comm = nullptr;
   double last_cost = 0, last_gmax = 0;
   size_t chol_lds = 0;
-  double* ls_buf = nullptr;      // line search scalars: [0] step2 [1] x2 (local) | [2] step2 [3] x2 [4] dir (points, all-reduced) | [5] dir (local)
+  double* ls_buf = nullptr;      // line search scalars, all-reduced: [0] |step|^2 [1] |x|^2 [2] grad . dir (each: this rank's points; rank 0 adds the replicated camera + pose part)
+  double* dirmax_buf = nullptr;  // [0..63] per-rank max |point step| (one-hot slots, all-reduced), [64] max |reduced step| (replicated)
+  bool trace = false;            // LIFCAL_TRACE=1: one stderr line per host decision of the LM loop, tagged with the rank
   double* Lpanel = nullptr; size_t bandw_lds = 0, backw_lds = 0; bool bandw_ok = false;
   // profiling: 5 events per sweep (start, after tables, after k_sweep, before k_schur, after k_schur, end)
   std::vector<hipEvent_t> prof_events; uint32_t prof_cap = 0, prof_used = 0; bool prof_on = false;
@@ -311,7 +314,7 @@ int launch_apply_step(lifcal_ba_handle* h, double t) {
   Dev& d = h->d;
   HIP_TRY(hipMemsetAsync(h->ls_buf, 0, 8 * sizeof(double), h->stream));
   const uint32_t n = std::max(std::max(6 * d.F, 17u), std::max(d.n_owned, d.Q));
-  hipLaunchKernelGGL(k_apply_step, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, t, h->ls_buf, h->ls_buf + 2);
+  hipLaunchKernelGGL(k_apply_step, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, t, h->ls_buf);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -329,18 +332,18 @@ int eval_trial(lifcal_ba_handle* h, double t, double radius, LsSample* smp) {
   if (!rc) rc = do_allreduce(h, h->red_block, h->red_count);
   if (!rc) {
     const uint32_t n = std::max(d.n_red, d.n_owned);
-    hipLaunchKernelGGL(k_dirderiv, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, h->ls_buf + 5, h->ls_buf + 4);
+    hipLaunchKernelGGL(k_dirderiv, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, h->ls_buf + 2);
     if (hipGetLastError() != hipSuccess) rc = LIFCAL_BA_ERR_HIP;
   }
   swap_all();
   if (rc) return rc;
-  if (int rc2 = do_allreduce(h, h->ls_buf + 2, 3)) return rc2;
+  if (int rc2 = do_allreduce(h, h->ls_buf, 3)) return rc2;
   double hb[8], cost;
   HIP_TRY(hipMemcpyAsync(hb, h->ls_buf, sizeof(hb), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(&cost, d.scal + SCAL_COST, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   smp->x = t; smp->value = cost; smp->value_valid = std::isfinite(cost);
-  smp->gradient = hb[4] + hb[5]; smp->gradient_valid = smp->value_valid && std::isfinite(smp->gradient);
+  smp->gradient = hb[2]; smp->gradient_valid = smp->value_valid && std::isfinite(smp->gradient);
   return 0;
 }
 
@@ -351,7 +354,9 @@ int read_step_scalars(lifcal_ba_handle* h, StepScalars* s) {
   HIP_TRY(hipMemcpyAsync(h->h_scal + ST_N, h->partial, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   const double* a = h->h_scal; const double* p = h->h_scal + ST_N;
-  s->gtd = a[ST_GTD] + p[0]; s->ddd = a[ST_DDD] + p[1]; s->step2 = a[ST_STEP2] + p[2]; s->x2 = a[ST_X2] + p[3];
+  // p[0..3]: all-reduced sums over every rank's points + the replicated camera / pose part contributed by rank 0 alone
+  // (k_update_reduced): identical bits on every rank, as the branches they steer require
+  s->gtd = p[0]; s->ddd = p[1]; s->step2 = p[2]; s->x2 = p[3];
   s->cand_cost = p[4]; s->chol_fail = a[ST_CHOL_FAIL];
   return 0;
 }
@@ -529,6 +534,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   const uint32_t split_obs = getenv("LIFCAL_GROUP_SPLIT") ? (uint32_t)std::max(0, atoi(getenv("LIFCAL_GROUP_SPLIT"))) : UINT32_MAX;
   // the wave-specialised kernel wants the lanes of a pass sorted by frame, k_sweep2 (LIFCAL_SWEEP_KERNEL=2) by point
   h->use_sweep3 = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
+  h->trace = getenv("LIFCAL_TRACE") != nullptr;
   PlanClock cclk;
   int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs, h->use_sweep3);
   if (rc) { delete h; return rc; }
@@ -639,8 +645,8 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
     }
   }
   A(d.dbg, (size_t)std::max(1u, d.n_blocks) * 32);
-  A(d.dP, 3 * (size_t)d.P); A(h->ls_buf, 8);
-  A(d.step, ST_N); A(h->partial, 8); A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->pts_gather, 3 * (size_t)d.P);
+  A(d.dP, 3 * (size_t)d.P); A(h->ls_buf, 8); A(h->dirmax_buf, 65);
+  A(d.step, ST_N); A(h->partial, 8); A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->stats_slots, 4 + 2 * 64); A(h->pts_gather, 3 * (size_t)d.P);
   // Cholesky panel: LDS when it fits (<= 64 KiB by default launch limits), else a global scratch
   const size_t panel_rows = 6 * (size_t)d.bw + d.NA + 1;
   const size_t lds_need = (80 + panel_rows * 6) * sizeof(double);
@@ -866,6 +872,7 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
     s->seconds_linear_solve += now_s() - t0;
     // model_cost_change = -g^T d - 1/2 d^T J^T J d with (J^T J + Lambda) d = -g  =>  1/2 (d^T Lambda d - g^T d)
     const double model_cost_change = 0.5 * (st.ddd - st.gtd);
+    if (h->trace) fprintf(stderr, "[lifcal_ba r%d] it %d radius %.17g x_cost %.17g cand %.17g gtd %.17g ddd %.17g step2 %.17g chol_fail %g bad %g\n", o.rank, iteration, radius, x_cost, st.cand_cost, st.gtd, st.ddd, st.step2, st.chol_fail, bad);
     const bool valid = st.chol_fail == 0.0 && bad == 0.0 && std::isfinite(model_cost_change) && model_cost_change > 0.0;
     if (!valid) {
       if (++invalid_steps >= 5) { s->termination = LIFCAL_BA_TERM_INVALID_STEPS; break; }
@@ -887,13 +894,25 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
         LsSample init, prev, cur;
         init.x = 0; init.value = x_cost; init.gradient = g0; init.value_valid = init.gradient_valid = true;
         if (int rc = eval_trial(h, 1.0, radius, &cur)) return rc;
-        // max |delta| for the minimum-step test
-        std::vector<double> dr(h->d.n_red), dp(3 * (size_t)h->d.P);
-        HIP_TRY(hipMemcpy(dr.data(), h->d.delta_red, dr.size() * 8, hipMemcpyDeviceToHost));
-        if (h->d.use_points && h->d.P) HIP_TRY(hipMemcpy(dp.data(), h->d.dP, dp.size() * 8, hipMemcpyDeviceToHost));
-        double dir_max = 0; for (double vv : dr) dir_max = std::max(dir_max, std::fabs(vv));
-        if (h->d.use_points) for (uint32_t q : h->plan.owned_points) if (h->plan.promoted[q] < 0) for (int k = 0; k < 3; ++k) dir_max = std::max(dir_max, std::fabs(dp[3 * (size_t)q + k]));
+        // max |delta| over ALL columns for the minimum-step test (ceres LineSearch::min_step_size / max_abs(direction)):
+        // the camera + pose part is replicated, the point part is spread over the ranks -> per-rank slots, all-reduced.
+        // (A rank-local maximum here once let one rank leave the search while the other entered the next trial's all-reduce.)
+        double dir_max = 0;
+        {
+          Dev& d = h->d;
+          HIP_TRY(hipMemsetAsync(h->dirmax_buf, 0, 65 * sizeof(double), h->stream));
+          const uint32_t n = std::max(std::max(d.n_red, d.n_owned), 1u);
+          hipLaunchKernelGGL(k_dir_max, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, (unsigned long long*)h->dirmax_buf);
+          HIP_TRY(hipGetLastError());
+          if (int rc = do_allreduce(h, h->dirmax_buf, 65)) return rc;
+          double hm[65];
+          HIP_TRY(hipMemcpyAsync(hm, h->dirmax_buf, sizeof(hm), hipMemcpyDeviceToHost, h->stream));
+          HIP_TRY(hipStreamSynchronize(h->stream));
+          for (int r = 0; r < o.world_size; ++r) dir_max = std::max(dir_max, hm[r]);
+          dir_max = std::max(dir_max, hm[64]);
+        }
         int ls_iter = 0; bool ls_ok = true;
+        if (h->trace) fprintf(stderr, "[lifcal_ba r%d] it %d line search: dir_max %.17g phi(1) %.17g phi'(1) %.17g\n", o.rank, iteration, dir_max, cur.value, cur.gradient);
         while (!cur.value_valid || cur.value > x_cost + suff * g0 * cur.x) {
           if (++ls_iter >= 20) { ls_ok = false; break; }
           const double lo_b = 1e-3 * cur.x, hi_b = 0.6 * cur.x;
@@ -903,6 +922,7 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
           if (tnew * dir_max < 1e-9) { ls_ok = false; break; }
           prev = cur;
           if (int rc = eval_trial(h, tnew, radius, &cur)) return rc;
+          if (h->trace) fprintf(stderr, "[lifcal_ba r%d] it %d line search trial %d: t %.17g phi %.17g phi' %.17g\n", o.rank, iteration, ls_iter, tnew, cur.value, cur.gradient);
         }
         const double t_opt = ls_ok ? cur.x : 1.0;
         // candidate at the chosen step length, its cost and the step norm (the model cost change stays that of the full step)
@@ -922,13 +942,13 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
           if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
           HIP_TRY(hipGetLastError());
           if (int rc = do_allreduce(h, h->partial, 8)) return rc;
-          if (int rc = do_allreduce(h, h->ls_buf + 2, 2)) return rc;
+          if (int rc = do_allreduce(h, h->ls_buf, 2)) return rc;
           double hb[8], hp[8];
           HIP_TRY(hipMemcpyAsync(hb, h->ls_buf, sizeof(hb), hipMemcpyDeviceToHost, h->stream));
           HIP_TRY(hipMemcpyAsync(hp, h->partial, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
           HIP_TRY(hipStreamSynchronize(h->stream));
           cand_cost = std::isfinite(hp[4]) ? hp[4] : std::numeric_limits<double>::max();
-          step2 = hb[0] + hb[2]; x2 = hb[1] + hb[3];
+          step2 = hb[0]; x2 = hb[1];
         }
         system_ready = false;   // the trial sweeps overwrote the blocks of the current point
         if (getenv("LIFCAL_DEBUG_LS")) fprintf(stderr, "[lifcal_ba] line search: %d backtracks, t = %.6g\n", ls_iter, t_opt);
@@ -954,6 +974,7 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
     }
     if (o.verbose) printf("%4d % .6e   % .2e %10.2e  %9.2e  %9.2e %9.2e\n", iteration, x_cost, cost_change, gmax, step_norm, rel, radius);
   }
+  if (h->trace) fprintf(stderr, "[lifcal_ba r%d] done: it %d termination %d cost %.17g\n", o.rank, iteration, (int)s->termination, x_cost);
   if (int rc = download_parameters(h)) return rc;
   s->iterations = iteration; s->final_cost = x_cost; s->final_radius = radius; s->final_gradient_max_norm = gmax;
   s->seconds_total = now_s() - t_start;
@@ -976,14 +997,23 @@ int lifcal_ba_reproj_stats(lifcal_ba_handle* h, double thr, lifcal_ba_stats* out
   }
   HIP_TRY(hipGetLastError());
   double hb[8];
-  if (h->opt.world_size > 1) {
-    // sums are all-reduced; the maxima travel as per-rank slots inside the same buffer would need world entries,
-    // so they are reduced through the sum of one-hot slots on the host instead: keep it simple and exact
-    if (int rc = do_allreduce(h, h->stats_buf, 4)) return rc;
-  }
   HIP_TRY(hipMemcpyAsync(hb, h->stats_buf, sizeof(hb), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
   double mx, my; std::memcpy(&mx, &hb[4], 8); std::memcpy(&my, &hb[5], 8);
+  if (h->opt.world_size > 1) {
+    // reference :1083-1084 takes the maxima over ALL observations: sums are all-reduced, the two maxima travel in one slot
+    // pair per rank (the other ranks' slots are 0, so the sum all-reduce moves them exactly) and the host takes the largest
+    std::vector<double> slots(4 + 2 * (size_t)h->opt.world_size, 0.0);
+    for (int k = 0; k < 4; ++k) slots[k] = hb[k];
+    slots[4 + 2 * (size_t)h->opt.rank] = mx; slots[5 + 2 * (size_t)h->opt.rank] = my;
+    HIP_TRY(hipMemcpyAsync(h->stats_slots, slots.data(), slots.size() * 8, hipMemcpyHostToDevice, h->stream));
+    if (int rc = do_allreduce(h, h->stats_slots, slots.size())) return rc;
+    HIP_TRY(hipMemcpyAsync(slots.data(), h->stats_slots, slots.size() * 8, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int k = 0; k < 4; ++k) hb[k] = slots[k];
+    mx = my = 0.0;
+    for (int r = 0; r < h->opt.world_size; ++r) { mx = std::max(mx, slots[4 + 2 * (size_t)r]); my = std::max(my, slots[5 + 2 * (size_t)r]); }
+  }
   const double n = hb[2];
   out->std_x = std::sqrt(hb[0] / n); out->std_y = std::sqrt(hb[1] / n); out->mae_x = mx; out->mae_y = my;
   out->num_points = (uint32_t)n; out->num_inliers = (uint32_t)hb[3];

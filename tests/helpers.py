@@ -34,6 +34,25 @@ def problem(sc, initial=True):
     return capi.ProblemArrays.from_scene(sc, initial=initial)
 
 
+def bounded_problem(sc):
+    """the recalib pattern with a tight box: fL and B fixed, bL0 / cx / cy boxed so closely that the projected LM step
+    fails ceres' Armijo test and TrustRegionMinimizer::DoLineSearch backtracks (checked on the oracle with LO_DEBUG_LS=1)"""
+    lower = np.full(17, -np.inf); upper = np.full(17, np.inf)
+    for k in (1, 3, 4):
+        lower[k] = sc.cam0[k] - 0.05 * abs(sc.cam_gt[k] - sc.cam0[k]) - 1e-3
+        upper[k] = sc.cam0[k] + 0.05 * abs(sc.cam_gt[k] - sc.cam0[k]) + 1e-3
+    return capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, sc.cam0, sc.views0, sc.pts0, sc.spx, sc.scale, sc.config,
+                              fixed_mask=0b101, lower=lower, upper=upper)
+
+
+def free_port():
+    """a TCP port the kernel just handed out (rendezvous of the multi-process tests)"""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def scaled_max_err(A, B, diag=None):
     """max |A-B| relative to sqrt(d_i d_j) with d the diagonal of B (block-scaled matrix comparison)."""
     d = np.sqrt(np.abs(np.diag(B if diag is None else diag))) + 1e-300

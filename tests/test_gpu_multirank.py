@@ -29,8 +29,13 @@ def _worker(rank, world, port, out_dir, spec_kw, mode):
         _, mk, _ = deformed_problem(spec_kw["stress_case"])
         pa = mk()
     else:
+        spec_kw = dict(spec_kw); bounded = spec_kw.pop("bounded", False)
         sc = scene.make_scene(scene.SceneSpec(**spec_kw))
-        pa = capi.ProblemArrays.from_scene(sc)
+        if bounded:
+            from tests.helpers import bounded_problem
+            pa = bounded_problem(sc)
+        else:
+            pa = capi.ProblemArrays.from_scene(sc)
     o = capi.default_options_py(); o.rank = rank; o.world_size = world
     ba = BundleAdjustment(pa, o)
 
@@ -66,7 +71,8 @@ def _worker(rank, world, port, out_dir, spec_kw, mode):
              S=sw.S if rank == 0 else np.zeros(1), rhs=sw.rhs if rank == 0 else np.zeros(1),
              gather_calls=calls["gather"], gather_doubles=calls["gather_doubles"], n_red=info.n_reduced,
              it=summ.iterations, term=summ.termination, final=summ.final_cost, n_local=info.n_obs_local,
-             stats=np.array([st.std_x, st.std_y, st.num_points, st.num_inliers]))
+             steps=np.array([summ.successful_steps, summ.unsuccessful_steps]),
+             stats=np.array([st.std_x, st.std_y, st.num_points, st.num_inliers, st.mae_x, st.mae_y]))
     ba.close()
     dist.barrier()
     dist.destroy_process_group()
@@ -82,9 +88,8 @@ def _worker(rank, world, port, out_dir, spec_kw, mode):
 def test_ranks_match_the_single_process_oracle(built, tmp_path, spec_kw, mode, world):
     import oracle
     from lifcal_amd import _capi as capi, scene
-    from tests.helpers import scaled_max_err, vec_err
-    port = 29700 + (os.getpid() % 1500)
-    mp.spawn(_worker, args=(world, port, str(tmp_path), spec_kw, mode), nprocs=world, join=True)
+    from tests.helpers import free_port, scaled_max_err, vec_err
+    mp.spawn(_worker, args=(world, free_port(), str(tmp_path), spec_kw, mode), nprocs=world, join=True)
     r0 = np.load(os.path.join(str(tmp_path), "rank0.npz")); r1 = np.load(os.path.join(str(tmp_path), f"rank{world - 1}.npz"))
     if mode == "allgather" and not spec_kw.get("n_constraints"):
         # the reduced block went through the slab exchange, and a slab is well below the whole block
@@ -109,6 +114,9 @@ def test_ranks_match_the_single_process_oracle(built, tmp_path, spec_kw, mode, w
     assert np.array_equal(r0["pts"], r1["pts"]) and np.array_equal(r0["cam"], r1["cam"])
     stt, err = oracle.reproj_stats(capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, r0["cam"], r0["views"], r0["pts"], sc.spx, sc.scale, sc.config), want_errors=True)
     assert abs(float(r0["stats"][0]) - stt.std_x) < 1e-9 and int(r0["stats"][2]) == sc.n_obs
+    # the maxima (reference CameraCalibration.cpp:1083-1084) are over ALL observations, on every rank
+    for r in (r0, r1):
+        assert abs(float(r["stats"][4]) - stt.mae_x) < 1e-9 and abs(float(r["stats"][5]) - stt.mae_y) < 1e-9
     # lifcal_ba_project_observations: a rank fills the observations of the points it owns (NaN elsewhere); together the ranks
     # cover every observation exactly once, with the projection of the final parameters
     xs = np.stack([np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))["xp"] for r in range(world)])
@@ -117,16 +125,15 @@ def test_ranks_match_the_single_process_oracle(built, tmp_path, spec_kw, mode, w
     assert np.max(np.abs(np.nansum(xs, 0) - (sc.u + err[:, 0]))) < 1e-8
 
 
-@pytest.mark.parametrize("k,world", [(11, 2), (22, 3), (26, 4), (37, 2), (41, 3)])   # (multiples of 5 are the big scenes of the family: too slow for the oracle here)
+@pytest.mark.parametrize("k,world", [(10, 2), (11, 2), (22, 3), (26, 4), (37, 2), (41, 3)])   # 10: recalib (bounds + fixed mask), 131 frames, one 364-observation group
 def test_slab_exchange_on_deformed_scenes(built, tmp_path, k, world):
     """ragged / tiny / wide-window scenes: ranks with few or no frames of their own, every rank must end with the
     single-process reduced system and solve"""
     import oracle
-    from tests.helpers import scaled_max_err, vec_err
+    from tests.helpers import free_port, scaled_max_err, vec_err
     from tests.test_gpu_stress import deformed_problem
     spec, mk, n = deformed_problem(k)
-    port = 29700 + ((os.getpid() + 7 * k) % 1500)
-    mp.spawn(_worker, args=(world, port, str(tmp_path), {"stress_case": k}, "allgather"), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, free_port(), str(tmp_path), {"stress_case": k}, "allgather"), nprocs=world, join=True)
     ref = oracle.sweep(mk(), radius=1e4, threads=4)
     so = oracle.solve(mk(), threads=4)
     r0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
@@ -137,3 +144,34 @@ def test_slab_exchange_on_deformed_scenes(built, tmp_path, k, world):
         rr = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
         assert (int(rr["it"]), int(rr["term"])) == (so.iterations, so.termination)
         assert abs(float(rr["final"]) - so.final_cost) <= 1e-7 * so.final_cost
+    # reprojection statistics of the common result: sums AND maxima are those of all observations on every rank
+    pf = mk(); pf.cam[:] = r0["cam"]; pf.views[:] = r0["views"]; pf.pts[:] = r0["pts"]
+    stt = oracle.reproj_stats(pf)
+    for r in range(world):
+        rr = np.load(os.path.join(str(tmp_path), f"rank{r}.npz"))
+        assert abs(float(rr["stats"][0]) - stt.std_x) < 1e-9 and int(rr["stats"][2]) == n
+        assert abs(float(rr["stats"][4]) - stt.mae_x) < 1e-9 and abs(float(rr["stats"][5]) - stt.mae_y) < 1e-9
+
+
+@pytest.mark.parametrize("spec_kw,world", [
+    (dict(n_frames=8, n_points=60, window=None, config=0xF06, seed=1320, outlier_fraction=0.02, bounded=True), 2),   # 12 backtracks, leaves through the minimum-step test
+    (dict(n_frames=16, n_points=100, window=5, config=0xF06, seed=1322, outlier_fraction=0.02, bounded=True), 3),    # several searches with one backtrack each
+], ids=["min_step_exit", "windowed_three_ranks"])
+def test_bounded_problems_backtrack_in_lockstep(built, tmp_path, spec_kw, world):
+    """BASELINE configs[4]'s code path (recalib: fixed mask + box bounds) at world size > 1 with a box tight enough that the
+    Armijo line search runs: every trial is a fused sweep with two all-reduces, so all ranks must take every branch of the
+    search together (the largest step component, the interpolated step lengths and the exit test are global quantities)."""
+    import oracle
+    from lifcal_amd import scene
+    from tests.helpers import bounded_problem, free_port
+    mp.spawn(_worker, args=(world, free_port(), str(tmp_path), spec_kw, "allgather"), nprocs=world, join=True)
+    kw = dict(spec_kw); kw.pop("bounded")
+    pb = bounded_problem(scene.make_scene(scene.SceneSpec(**kw)))
+    so = oracle.solve(pb, threads=4)
+    rs = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(world)]
+    for rr in rs:
+        assert (int(rr["it"]), int(rr["term"])) == (so.iterations, so.termination)
+        assert (int(rr["steps"][0]), int(rr["steps"][1])) == (so.successful_steps, so.unsuccessful_steps)
+        assert abs(float(rr["final"]) - so.final_cost) <= 1e-8 * so.final_cost
+        assert np.allclose(rr["cam"][:5], pb.cam[:5], rtol=1e-6)
+        assert np.array_equal(rr["cam"], rs[0]["cam"]) and np.array_equal(rr["views"], rs[0]["views"]) and np.array_equal(rr["pts"], rs[0]["pts"])
