@@ -55,41 +55,68 @@ def accumulate_kernel_bytes(n_obs, n_points, n_frames):
     return n_obs * 40 + (24 * n_points + 48 * n_frames + 8 * 17)
 
 
-def cpu_baseline(sample_name="cfg3"):
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sc, pa, budget_s=25.0):
+    """The CPU restatement (oracle/, kind "port": real Ceres is not in the image) on THIS host's cores, on the identical flattened
+    input the GPU sweep was timed on (SURVEY.md 8d): the dual-number arm (what ceres::AutoDiffCostFunction evaluates on the
+    reference's functor — `value`) and the analytic-Jacobian arm with per-lens / per-frame tables (oracle/analytic.hpp), both
+    followed by the same dense Schur elimination, all host threads (reference CameraCalibration.cpp:961).  Secondary: a full solve
+    of BASELINE configs[2] (cfg3) with the dual-number arm."""
     import oracle
     from lifcal_amd import _capi as capi, scene
-    sc = scene.make_scene(scene.baseline_spec(sample_name))
-    pa = capi.ProblemArrays.from_scene(sc)
     threads = max(1, min(oracle.hardware_threads(), len(os.sched_getaffinity(0))))
-    oracle.sweep(pa, radius=1e4, threads=threads, want_matrices=False)  # warm-up (page faults, thread start)
-    best = None
-    t_end = time.time() + 20.0
-    reps = 0
-    while reps < 3 or (time.time() < t_end and reps < 12):
-        r = oracle.sweep(pa, radius=1e4, threads=threads, want_matrices=False)
-        best = r.seconds if best is None else min(best, r.seconds)
-        reps += 1
-    # the same CPU restatement through a full solve of the sample (works on a private copy of the parameters)
-    t0 = time.perf_counter()
-    summ = oracle.solve(pa, threads=threads)
-    t_solve = time.perf_counter() - t0
-    st = oracle.reproj_stats(pa, 1.0)
-    return {"value": sc.n_obs / best, "unit": "obs/s", "cores": threads, "kind": "port",
-            "sample": f"{sample_name}: {sc.spec.n_frames} frames, {sc.spec.n_points} points, {sc.n_obs} obs, config {sc.config:#x}; "
-                      f"dual-number Jacobian + dense Schur sweep, best of {reps}",
-            "solve": {"seconds": t_solve, "iterations": int(summ.iterations), "final_cost": float(summ.final_cost),
-                      "final_rms_reproj_px": [float(st.std_x), float(st.std_y)]}}
+
+    def arm(analytic, budget):
+        oracle.sweep(pa, radius=1e4, threads=threads, want_matrices=False, analytic=analytic)   # warm-up (page faults, thread start)
+        best, reps, t_end = None, 0, time.time() + budget
+        while reps < 2 or (time.time() < t_end and reps < 10):
+            r = oracle.sweep(pa, radius=1e4, threads=threads, want_matrices=False, analytic=analytic)
+            if best is None or r.seconds < best.seconds:
+                best = r
+            reps += 1
+        return {"value": sc.n_obs / best.seconds, "unit": "obs/s", "seconds": best.seconds, "seconds_jacobian": best.seconds_eval,
+                "seconds_schur": best.seconds_schur, "best_of": reps}
+    dual = arm(False, 0.5 * budget_s)
+    ana = arm(True, 0.3 * budget_s)
+    out = {"value": dual["value"], "unit": "obs/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
+           "sample": f"the whole bench workload, identical flattened input: {sc.spec.n_frames} frames, {sc.spec.n_points} points, {sc.n_obs} obs, "
+                     f"config {sc.config:#x}; one Jacobian + dense-Schur sweep, dual-number (autodiff-equivalent) Jacobian, best of {dual['best_of']}",
+           "arms": {"dual_number": dual, "analytic": ana}}
+    try:   # secondary: the same CPU restatement through a full solve of a smaller BASELINE config (works on a private copy)
+        sc3 = scene.make_scene(scene.baseline_spec("cfg3"))
+        pa3 = capi.ProblemArrays.from_scene(sc3)
+        t0 = time.perf_counter()
+        summ = oracle.solve(pa3, threads=threads)
+        t_solve = time.perf_counter() - t0
+        st = oracle.reproj_stats(pa3, 1.0)
+        out["solve_cfg3"] = {"observations": sc3.n_obs, "seconds": t_solve, "iterations": int(summ.iterations), "final_cost": float(summ.final_cost),
+                             "final_rms_reproj_px": [float(st.std_x), float(st.std_y)]}
+    except Exception as e:  # noqa: BLE001
+        out["solve_cfg3"] = {"error": repr(e)}
+    return out
 
 
 def load_traffic(workload):
-    """HBM bytes per launch of the dominant kernel from committed rocprofv3 PMC passes (profiles/), or None."""
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json: counters cannot
+    be collected inside this process), and where they came from; (None, None) if absent."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        return t.get(workload, {}).get("k_sweep_hbm_bytes")
+        e = t.get(workload, {})
+        return e.get("k_sweep_hbm_bytes"), "profiles/traffic.json <- " + str(e.get("source", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes"))
     except Exception:
-        return None
+        return None, None
 
 
 def main():
@@ -98,6 +125,9 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="metric")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = rank r adds the r-th copy of the workload along the trajectory (default, per-GPU work fixed); "
+                         "strong = ONE problem (e.g. --workload cfg4: BASELINE configs[3], 1000 frames / 50 k points) sharded by 3D point over the N ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the full LM solve after the timed sweeps (profiling runs: only sweep kernels in the trace)")
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
@@ -131,7 +161,8 @@ def main():
 
     spec = scene.baseline_spec(args.workload)
     sc = scene.make_scene(spec)
-    pa = tiled_problem(sc, world) if world > 1 else capi.ProblemArrays.from_scene(sc)
+    strong = args.scaling == "strong" and world > 1
+    pa = tiled_problem(sc, world) if (world > 1 and not strong) else capi.ProblemArrays.from_scene(sc)
     n_obs_total = int(pa.struct.n_obs)
     o = capi.default_options_py()
     o.device = local_rank
@@ -261,11 +292,13 @@ def main():
 
     out = None
     if rank == 0:
-        F_tot, P_tot = spec.n_frames * world, spec.n_points * world
+        copies = 1 if strong else world
+        F_tot, P_tot = spec.n_frames * copies, spec.n_points * copies
         n_loc = info.n_obs_local
         n_red = 17 + 6 * F_tot
-        b_kernel = accumulate_kernel_bytes(n_loc, spec.n_points, spec.n_frames)
-        b_sweep = algorithmic_bytes(n_loc, spec.n_points, spec.n_frames, 17 + 6 * spec.n_frames)
+        p_loc = info.n_points_local if strong else spec.n_points   # per-rank share of the algorithmic bytes (rank 0's shard)
+        b_kernel = accumulate_kernel_bytes(n_loc, p_loc, spec.n_frames)
+        b_sweep = algorithmic_bytes(n_loc, p_loc, spec.n_frames, 17 + 6 * spec.n_frames)
         t_kernel = prof.ms_accumulate * 1e-3
         t_total = prof.ms_total * 1e-3
         achieved = b_kernel / t_kernel / 1e9
@@ -275,14 +308,14 @@ def main():
             "unit": "obs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {F_tot} frames, {P_tot} points, {n_obs_total} micro-image observations, "
                                    f"window {spec.window}, config {spec.config:#x} (2 radial + tangential, mlCenterAdj, Cauchy(0.5), refine poses+points)",
                        "obs_per_gpu": n_loc, "n_reduced": n_red, "sharding": "by 3D point" if world > 1 else "single GPU", "comm": comm_used},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (residual+Jacobian+block accumulation)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
-                         "traffic": load_traffic(args.workload),
+                         "traffic": load_traffic(args.workload)[0], "traffic_source": load_traffic(args.workload)[1],
                          "algorithmic_bytes_per_launch": b_kernel, "kernel_ms": prof.ms_accumulate,
                          "whole_sweep": {"algorithmic_bytes": b_sweep, "ms": prof.ms_total, "ms_schur": prof.ms_schur, "ms_tables": prof.ms_tables,
                                          "achieved": b_sweep / t_total / 1e9, "frac": b_sweep / t_total / HBM_PEAK}},
@@ -296,7 +329,7 @@ def main():
         out["cpu_baseline"] = None
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(sc, capi.ProblemArrays.from_scene(sc))
             except Exception as e:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out))

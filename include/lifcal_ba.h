@@ -193,10 +193,11 @@ int lifcal_ba_sweep_enqueue(lifcal_ba_handle* h, double radius);
  * begin() reserves event pairs for up to max_sweeps sweeps; end() synchronises and averages. */
 typedef struct lifcal_ba_profile {
   uint32_t n_sweeps;
-  double ms_tables;       /* camera constants + frame table + lens table                         */
-  double ms_accumulate;   /* k_sweep: residual + Jacobian + block accumulation (dominant kernel) */
-  double ms_schur;        /* k_schur: point-block inverse + Schur complement                      */
-  double ms_total;        /* first kernel of a sweep to the end of k_finalize                     */
+  double ms_tables;       /* k_tables: camera constants + frame table + lens table + zero fill of the reduced block   */
+  double ms_accumulate;   /* the dominant kernel(s): k_sweep3 (fused residual + Jacobian + accumulation + point elimination
+                             of the regular points) [+ k_sweep for special points]                                    */
+  double ms_schur;        /* everything behind it: constraints, k_schur (special points), exchange, k_finalize         */
+  double ms_total;        /* first kernel of the first sweep to the end of the last one, divided by the sweep count    */
 } lifcal_ba_profile;
 int lifcal_ba_profile_begin(lifcal_ba_handle* h, uint32_t max_sweeps);
 int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out);

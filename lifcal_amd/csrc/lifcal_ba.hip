@@ -227,7 +227,7 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
 // one Jacobian + Schur sweep at the current point and the given trust-region radius
 int launch_sweep(lifcal_ba_handle* h, double radius) {
   Dev& d = h->d;
-  if (h->prof_active() && h->prof_used == 0) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));
+  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));
   // the table kernel also zero-fills the reduced block and the step scalars
   if (int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true, h->red_block, h->red_count, d.step, ST_N)) return rc;
   bool zeroed = true;
@@ -759,17 +759,18 @@ int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out) {
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::memset(out, 0, sizeof(*out));
   const uint32_t n = h->prof_used;
-  for (uint32_t i = 0; i < n; ++i) {   // per sweep: events 1 / 2 bracket the dominant kernel(s) (k_sweep2 [+ k_sweep])
-    float bms = 0;
+  for (uint32_t i = 0; i < n; ++i) {   // per sweep: events 0 | tables + zero fill | 1 | dominant kernel(s) | 2 | everything after it | 5
+    float a = 0, bms = 0, c = 0;
     hipEvent_t* e = &h->prof_events[(size_t)i * 6];
+    HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
     HIP_TRY(hipEventElapsedTime(&bms, e[1], e[2]));
-    out->ms_accumulate += bms;
+    HIP_TRY(hipEventElapsedTime(&c, e[2], e[5]));
+    out->ms_tables += a; out->ms_accumulate += bms; out->ms_schur += c;
   }
   if (n) {
-    float t = 0;   // first kernel of the first sweep -> end of the last sweep
+    float t = 0;   // first kernel of the first sweep -> end of the last sweep (includes the gaps between sweeps)
     HIP_TRY(hipEventElapsedTime(&t, h->prof_events[0], h->prof_events[(size_t)(n - 1) * 6 + 5]));
-    out->ms_total = t / n; out->ms_accumulate /= n;
-    out->ms_tables = 0.0; out->ms_schur = 0.0;
+    out->ms_total = t / n; out->ms_accumulate /= n; out->ms_tables /= n; out->ms_schur /= n;
   }
   out->n_sweeps = n;
   h->prof_on = false;

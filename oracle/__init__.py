@@ -20,7 +20,7 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("lifcal_oracle.cpp", "lifcal_mla.cpp", "model.hpp", "jet.hpp", "lifcal_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("lifcal_oracle.cpp", "lifcal_mla.cpp", "model.hpp", "analytic.hpp", "jet.hpp", "lifcal_oracle.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "lifcal_ba.h"))
     stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
     if stale:
@@ -43,6 +43,7 @@ def lib() -> C.CDLL:
         L.lo_residuals.argtypes = [C.POINTER(capi.Problem), dp]
         L.lo_reduced_size.argtypes = [C.POINTER(capi.Problem), capi.uptr, capi.uptr]
         L.lo_sweep.argtypes = [C.POINTER(capi.Problem), C.POINTER(capi.Options), d, C.c_int, C.POINTER(capi.SweepOut), dp, dp]
+        L.lo_sweep_analytic.argtypes = L.lo_sweep.argtypes
         L.lo_solve.argtypes = [C.POINTER(capi.Problem), C.POINTER(capi.Options), C.c_int, C.POINTER(capi.Summary)]
         L.lo_reproj_stats.argtypes = [C.POINTER(capi.Problem), d, C.POINTER(capi.Stats), dp]
         L.lo_hardware_threads.restype = C.c_int
@@ -129,7 +130,9 @@ class SweepResult:
     pass
 
 
-def sweep(pa: capi.ProblemArrays, radius=1e4, options=None, threads=1, want_matrices=True) -> SweepResult:
+def sweep(pa: capi.ProblemArrays, radius=1e4, options=None, threads=1, want_matrices=True, analytic=False) -> SweepResult:
+    """One Jacobian + Schur sweep.  analytic=False: dual numbers through the functor, as ceres::AutoDiffCostFunction evaluates the
+    reference's residual blocks; analytic=True: hand-derived Jacobian with per-lens / per-frame tables (oracle/analytic.hpp)."""
     o = options if options is not None else capi.default_options_py()
     n, m = reduced_size(pa)
     res = SweepResult()
@@ -140,7 +143,8 @@ def sweep(pa: capi.ProblemArrays, radius=1e4, options=None, threads=1, want_matr
         out.S, out.rhs, out.gradient_reduced = _dp(res.S), _dp(res.rhs), _dp(res.gradient_reduced)
         out.point_gradient, out.point_hessian_inv = _dp(res.point_gradient), _dp(res.point_hessian_inv)
     te = np.zeros(1); ts = np.zeros(1)
-    rc = lib().lo_sweep(C.byref(pa.struct), C.byref(o), radius, threads, C.byref(out), _dp(te), _dp(ts))
+    fn = lib().lo_sweep_analytic if analytic else lib().lo_sweep
+    rc = fn(C.byref(pa.struct), C.byref(o), radius, threads, C.byref(out), _dp(te), _dp(ts))
     res.rc = rc
     res.cost = out.cost; res.gradient_max_norm = out.gradient_max_norm
     res.n_reduced = n; res.n_promoted = m

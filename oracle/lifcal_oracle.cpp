@@ -29,11 +29,13 @@
 #include <cstring>
 #include <limits>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../include/lifcal_ba.h"
 #include "lifcal_oracle.h"
 #include "model.hpp"
+#include "analytic.hpp"
 
 namespace {
 
@@ -105,6 +107,22 @@ struct Structure {
         pt_cons[pr->c_i[c]].push_back(c); pt_cons[pr->c_j[c]].push_back(c);
         pt_used[pr->c_i[c]] = 1; pt_used[pr->c_j[c]] = 1;
       }
+  }
+  // analytic arm: unique micro-lens centres (exact bit patterns) and the lens of every observation, built on first use
+  mutable std::vector<int> lens_of_obs; mutable std::vector<double> lens_xy;
+  void build_lenses() const {
+    if (!lens_of_obs.empty() || N == 0) return;
+    lens_of_obs.resize(N);
+    struct Key { uint64_t a, b; bool operator==(const Key& o) const { return a == o.a && b == o.b; } };
+    struct Hash { size_t operator()(const Key& k) const { return (size_t)(k.a * 0x9E3779B97F4A7C15ull ^ (k.b + 0x7F4A7C15ull + (k.a << 6))); } };
+    std::unordered_map<Key, int, Hash> map;
+    map.reserve(1 << 16);
+    for (int i = 0; i < N; ++i) {
+      Key k; std::memcpy(&k.a, &p->mcx[i], 8); std::memcpy(&k.b, &p->mcy[i], 8);
+      auto it = map.find(k);
+      if (it == map.end()) { it = map.emplace(k, (int)(lens_xy.size() / 2)).first; lens_xy.push_back(p->mcx[i]); lens_xy.push_back(p->mcy[i]); }
+      lens_of_obs[i] = it->second;
+    }
   }
   int view_col(int f) const { return NC + 6 * f; }
   int prom_col(int k) const { return NC + 6 * F + 3 * k; }
@@ -182,9 +200,19 @@ inline void cauchy(double a, double s, double& rho0, double& rho1) {
 }
 
 double evaluate(const Structure& s, const double* cam, const double* views, const double* pts,
-                double loss_scale, int threads, Eval* out /* null: cost only */) {
+                double loss_scale, int threads, Eval* out /* null: cost only */, bool analytic = false) {
   const int N = s.N;
   const bool jac = out != nullptr;
+  // analytic arm (oracle/analytic.hpp): camera constants once, one table entry per unique lens and per frame
+  lo::ACam acam; std::vector<lo::ALens> alens; std::vector<lo::AFrame> aframes;
+  analytic = analytic && jac;
+  if (analytic) {
+    s.build_lenses();
+    lo::acam_prepare(cam, s.cfg, s.p->spx, s.p->spy, s.p->scale, acam);
+    alens.resize(s.lens_xy.size() / 2); aframes.resize(s.F);
+    parallel_for(threads, (int64_t)alens.size(), [&](int64_t lo_, int64_t hi_, int) { for (int64_t l = lo_; l < hi_; ++l) lo::alens_eval(acam, s.lens_xy[2 * l], s.lens_xy[2 * l + 1], true, alens[l]); });
+    for (int f = 0; f < s.F; ++f) lo::aframe_eval(views + 6 * (size_t)f, aframes[f]);
+  }
   if (jac) {
     out->r.assign(2 * (size_t)N, 0.0);
     out->Jc.assign((size_t)N * 2 * NC, 0.0);
@@ -200,7 +228,27 @@ double evaluate(const Structure& s, const double* cam, const double* views, cons
       double* Jc = jac ? &out->Jc[(size_t)i * 2 * NC] : jc_tmp;
       double* Jv = (jac && s.use_poses) ? &out->Jv[(size_t)i * 12] : jv_tmp;
       double* Jp = (jac && s.use_points) ? &out->Jp[(size_t)i * 6] : jp_tmp;
-      eval_obs(s, (int)i, cam, views, pts, jac, r, Jc, Jv, Jp);
+      if (analytic) {
+        const lo::AFrame& fr = aframes[s.p->fr[i]];
+        const double* P = pts + 3 * (size_t)s.p->pt[i];
+        double pc[3], Jpc[2][3], Jth[2][17];
+        for (int a = 0; a < 3; ++a) pc[a] = fr.R[a][0] * P[0] + fr.R[a][1] * P[1] + fr.R[a][2] * P[2] + fr.t[a];
+        lo::aobs_eval(acam, alens[s.lens_of_obs[i]], pc, s.p->u[i], s.p->v[i], r, Jpc, Jth);
+        for (int a = 0; a < 2; ++a) {
+          for (int k = 0; k < NC; ++k) Jc[a * NC + k] = Jth[a][k];
+          if (s.use_poses) {
+            for (int k = 0; k < 3; ++k) {   // d(R P)/d angle_k = dR_k P
+              double g[3];
+              for (int b = 0; b < 3; ++b) g[b] = fr.dR[k][b][0] * P[0] + fr.dR[k][b][1] * P[1] + fr.dR[k][b][2] * P[2];
+              Jv[a * 6 + k] = Jpc[a][0] * g[0] + Jpc[a][1] * g[1] + Jpc[a][2] * g[2];
+              Jv[a * 6 + 3 + k] = Jpc[a][k];
+            }
+          }
+          if (s.use_points) for (int k = 0; k < 3; ++k) Jp[a * 3 + k] = Jpc[a][0] * fr.R[0][k] + Jpc[a][1] * fr.R[1][k] + Jpc[a][2] * fr.R[2][k];
+        }
+      } else {
+        eval_obs(s, (int)i, cam, views, pts, jac, r, Jc, Jv, Jp);
+      }
       const double sq = r[0] * r[0] + r[1] * r[1];
       if (s.cfg.robust) {
         double rho0, rho1; cauchy(loss_scale, sq, rho0, rho1);
@@ -784,13 +832,14 @@ int lo_reduced_size(const lifcal_ba_problem* p, uint32_t* n_reduced, uint32_t* n
 // One Jacobian + Schur sweep at `radius` with the Jacobi scaling of the current point
 // (= what ceres does in iteration 0/1).  Outputs follow include/lifcal_ba.h lifcal_ba_sweep_out:
 // UNSCALED space, S delta = rhs.
-int lo_sweep(const lifcal_ba_problem* p, const lifcal_ba_options* o, double radius, int threads,
-             lifcal_ba_sweep_out* out, double* seconds_eval, double* seconds_schur) {
+static int sweep_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, double radius, int threads,
+                      lifcal_ba_sweep_out* out, double* seconds_eval, double* seconds_schur, bool analytic) {
   if (int rc = validate(p)) return rc;
   Structure s(p);
+  if (analytic) s.build_lenses();   // problem set-up like the CSR above, outside the timed sweep
   Eval e;
   const double t0 = now_s();
-  evaluate(s, p->cam, p->views, p->pts, o->loss_scale, threads, &e);
+  evaluate(s, p->cam, p->views, p->pts, o->loss_scale, threads, &e, analytic);
   const double t1 = now_s();
   Columns grad, sqn, sigma, D2;
   gradient_and_norms(s, e, &grad, &sqn);
@@ -824,6 +873,16 @@ int lo_sweep(const lifcal_ba_problem* p, const lifcal_ba_options* o, double radi
       for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b)
         out->point_hessian_inv[9 * (size_t)pt + 3 * a + b] = (s.use_points && s.promoted[pt] < 0) ? lin.ete_inv[9 * (size_t)pt + 3 * a + b] * sigma.pt[3 * pt + a] * sigma.pt[3 * pt + b] : 0.0;
   return ok ? 0 : LIFCAL_BA_ERR_NUMERIC;
+}
+
+int lo_sweep(const lifcal_ba_problem* p, const lifcal_ba_options* o, double radius, int threads,
+             lifcal_ba_sweep_out* out, double* seconds_eval, double* seconds_schur) {
+  return sweep_impl(p, o, radius, threads, out, seconds_eval, seconds_schur, false);
+}
+// the same sweep with the analytic Jacobian arm (oracle/analytic.hpp) instead of dual numbers
+int lo_sweep_analytic(const lifcal_ba_problem* p, const lifcal_ba_options* o, double radius, int threads,
+                      lifcal_ba_sweep_out* out, double* seconds_eval, double* seconds_schur) {
+  return sweep_impl(p, o, radius, threads, out, seconds_eval, seconds_schur, true);
 }
 
 // ceres::Solve (TrustRegionMinimizer, LEVENBERG_MARQUARDT, DENSE_SCHUR); parameters updated in place

@@ -20,6 +20,9 @@ int lo_residuals(const lifcal_ba_problem* p, double* r2n);
 int lo_reduced_size(const lifcal_ba_problem* p, uint32_t* n_reduced, uint32_t* n_promoted);
 int lo_sweep(const lifcal_ba_problem* p, const lifcal_ba_options* o, double radius, int threads,
              lifcal_ba_sweep_out* out, double* seconds_eval, double* seconds_schur);
+/* the same sweep, residual blocks evaluated with the analytic Jacobian arm (oracle/analytic.hpp) instead of dual numbers */
+int lo_sweep_analytic(const lifcal_ba_problem* p, const lifcal_ba_options* o, double radius, int threads,
+                      lifcal_ba_sweep_out* out, double* seconds_eval, double* seconds_schur);
 int lo_solve(const lifcal_ba_problem* p, const lifcal_ba_options* o, int threads, lifcal_ba_summary* sum);
 int lo_reproj_stats(const lifcal_ba_problem* p, double thr, lifcal_ba_stats* out, double* errors_2n);
 int lo_hardware_threads(void);

@@ -1,4 +1,7 @@
-"""BASELINE.json configs[3] and configs[4] at FULL size on one GPU (fp64 arms).
+"""BASELINE.json configs at FULL size on one GPU (fp64 arms).
+
+configs[0] (5 frames x 100 points, intrinsics only, arity <2,17>) and configs[1] (20 frames x 500 points, 0x506): small enough
+for the oracle to form the reduced system and to solve, so they get the full parity treatment (sweep + trajectory).
 
 configs[3]: 1000 frames, 50 k points (~2.4 M micro-image observations with this MLA), 0xF06 — the problem the 8-GPU run
 shards; here the whole of it on one device.  configs[4]: recalib mode, 2000 frames, 100 k points (~4.8 M observations):
@@ -41,6 +44,40 @@ def check_solve(pa, fixed=(), lower=None, upper=None):
     if lower is not None:
         assert np.all(pa.cam >= lower) and np.all(pa.cam <= upper)
     return s, st
+
+
+@pytest.mark.parametrize("name", ["cfg1", "cfg2"])
+def test_cfg1_cfg2_sweep_and_solve_match_the_oracle(built, name):
+    from tests.helpers import scaled_max_err, vec_err
+    sc = scene.make_scene(scene.baseline_spec(name))
+    if name == "cfg1":
+        assert (sc.spec.n_frames, sc.spec.n_points, sc.config) == (5, 100, 0x006)      # BASELINE configs[0]: intrinsics only
+    else:
+        assert (sc.spec.n_frames, sc.spec.n_points, sc.config) == (20, 500, 0x506)     # BASELINE configs[1]
+    threads = oracle.hardware_threads()
+    ref = oracle.sweep(problem(sc), radius=1e4, threads=threads)
+    pa = problem(sc)
+    with BundleAdjustment(pa) as ba:
+        got = ba.sweep(1e4, want_matrices=True)
+        assert got.n_reduced == ref.S.shape[0]
+        assert abs(got.cost - ref.cost) <= 1e-12 * ref.cost
+        assert scaled_max_err(got.S, ref.S) < 1e-9 and vec_err(got.rhs, ref.rhs) < 1e-9
+        assert vec_err(got.gradient_reduced, ref.gradient_reduced) < 1e-10
+        if sc.config & 0x400:
+            assert vec_err(got.point_gradient, ref.point_gradient) < 1e-10
+        s = ba.performBundleAdjustment()
+        st = ba.calcReprojectionError()
+    pb = problem(sc)
+    so = oracle.solve(pb, threads=threads)
+    assert (s.iterations, s.successful_steps, s.unsuccessful_steps, s.termination) == (so.iterations, so.successful_steps, so.unsuccessful_steps, so.termination)
+    assert abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    live = 5 + (sc.config & 3) + (2 if sc.config & 4 else 0)
+    assert np.allclose(pa.cam[:live], pb.cam[:live], rtol=1e-6, atol=1e-12)           # north_star: within 1e-6 relative
+    assert np.all(pa.cam[live:] == 0.0)
+    assert np.allclose(pa.views, pb.views, rtol=0, atol=1e-6 * (1 + np.abs(pb.views).max()))
+    assert np.allclose(pa.pts, pb.pts, rtol=0, atol=1e-6 * (1 + np.abs(pb.pts).max()))
+    sto = oracle.reproj_stats(pb)
+    assert abs(st.std_x - sto.std_x) < 1e-8 and abs(st.std_y - sto.std_y) < 1e-8 and st.num_points == sc.n_obs
 
 
 def test_cfg4_whole_problem_on_one_gpu(built):
