@@ -158,6 +158,23 @@ IO_PROTOTYPES = {
     "lifcal_write_protocol": (C.c_int, [C.c_char_p, C.POINTER(Protocol)]),
 }
 
+class ColmapInfo(C.Structure):     # include/lifcal_colmap.h lifcal_colmap_info
+    _fields_ = [("n_frames", C.c_uint32), ("n_points", C.c_uint32), ("n_image_points", C.c_uint64), ("binary", C.c_int32),
+                ("camera_model_id", C.c_int32), ("width", C.c_int32), ("height", C.c_int32), ("reserved", C.c_int32),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("k1", C.c_double), ("k2", C.c_double), ("p1", C.c_double), ("p2", C.c_double), ("f", C.c_double)]
+
+
+# every symbol include/lifcal_colmap.h declares
+COLMAP_PROTOTYPES = {
+    "lifcal_colmap_read": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "lifcal_colmap_get_info": (C.c_int, [C.c_void_p, C.POINTER(ColmapInfo)]),
+    "lifcal_colmap_get_frames": (C.c_int, [C.c_void_p, _iptr, dptr, dptr, dptr]),
+    "lifcal_colmap_get_points": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), dptr]),
+    "lifcal_colmap_get_image_points": (C.c_int, [C.c_void_p, dptr, dptr, uptr, uptr]),
+    "lifcal_colmap_free": (None, [C.c_void_p]),
+}
+
 # every symbol include/lifcal_ba.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
     "lifcal_ba_default_options": (None, [C.POINTER(Options)]),
@@ -197,7 +214,7 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
                 "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 "There is no CPU fallback for the bundle-adjustment path.")
         lib = C.CDLL(path)
-        for name, (res, args) in list(PROTOTYPES.items()) + list(MLA_PROTOTYPES.items()) + list(IO_PROTOTYPES.items()):
+        for name, (res, args) in list(PROTOTYPES.items()) + list(MLA_PROTOTYPES.items()) + list(IO_PROTOTYPES.items()) + list(COLMAP_PROTOTYPES.items()):
             fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
             fn.restype = res
             fn.argtypes = args

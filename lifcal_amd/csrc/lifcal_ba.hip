@@ -1070,3 +1070,6 @@ int lifcal_ba_project_observations(lifcal_ba_handle* h, double* x_proj, double* 
 
 // LiFCal's result files (include/lifcal_io.h)
 #include "writers.hpp"
+
+// COLMAP sparse-model ingestion (include/lifcal_colmap.h)
+#include "colmap.hpp"

@@ -32,6 +32,11 @@ def test_library_exports_every_declared_symbol(built):
     assert declared3 == set(capi.IO_PROTOTYPES), (declared3 ^ set(capi.IO_PROTOTYPES))
     for name in sorted(declared3):
         assert hasattr(lib, name), f"{name} declared in include/lifcal_io.h but not exported"
+    hdr4 = open(os.path.join(ROOT, "include", "lifcal_colmap.h")).read()
+    declared4 = set(re.findall(r"\b(lifcal_colmap_[a-z_0-9]+)\s*\(", hdr4))
+    assert declared4 == set(capi.COLMAP_PROTOTYPES), (declared4 ^ set(capi.COLMAP_PROTOTYPES))
+    for name in sorted(declared4):
+        assert hasattr(lib, name), f"{name} declared in include/lifcal_colmap.h but not exported"
     assert b"gfx950" in lib.lifcal_ba_version()
 
 
