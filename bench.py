@@ -45,14 +45,14 @@ def tiled_problem(sc, copies):
                               sc.spx, sc.scale, sc.config, use_constraints=0)
 
 
-def algorithmic_bytes(n_obs, n_points, n_frames, n_red):
-    """B_alg = N*40 + 2*(24 P + 48 F + 8*17) + 8*n_red(n_red+1)/2 + 8*n_red  (fp64)."""
-    return n_obs * 40 + 2 * (24 * n_points + 48 * n_frames + 8 * 17) + 8 * (n_red * (n_red + 1) // 2) + 8 * n_red
+def algorithmic_bytes(n_obs, n_points, n_frames, n_red, b_obs=40):
+    """B_alg = N*b_obs + 2*(24 P + 48 F + 8*17) + 8*n_red(n_red+1)/2 + 8*n_red; b_obs = 40 (fp64) or 24 (precision = 1)."""
+    return n_obs * b_obs + 2 * (24 * n_points + 48 * n_frames + 8 * 17) + 8 * (n_red * (n_red + 1) // 2) + 8 * n_red
 
 
-def accumulate_kernel_bytes(n_obs, n_points, n_frames):
+def accumulate_kernel_bytes(n_obs, n_points, n_frames, b_obs=40):
     """share of B_alg the dominant kernel (k_sweep) must move: the observation stream + one parameter read."""
-    return n_obs * 40 + (24 * n_points + 48 * n_frames + 8 * 17)
+    return n_obs * b_obs + (24 * n_points + 48 * n_frames + 8 * 17)
 
 
 def cpu_model():
@@ -124,10 +124,16 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="metric")
+    ap.add_argument("--workload", default="metric_web",
+                    help="metric_web (default): the 1.0 M-observation point with the lenses of every image point chosen by the reference's own generator, "
+                         "projectPointsToRawImage, through its GPU port lifcal_mla_project; metric: the round-1 scene (K-nearest lens stand-in); cfg1..cfg5")
+    ap.add_argument("--lens-selection", choices=["auto", "web", "nearest"], default="auto", help="auto: web for *_web workloads, nearest otherwise")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = rank r adds the r-th copy of the workload along the trajectory (default, per-GPU work fixed); "
                          "strong = ONE problem (e.g. --workload cfg4: BASELINE configs[3], 1000 frames / 50 k points) sharded by 3D point over the N ranks")
+    ap.add_argument("--precision", type=int, choices=[0, 1], default=0,
+                    help="0: fp64 everywhere (the BASELINE metric configuration); 1: options.precision = 1, residual / Jacobian of an observation in fp32 "
+                         "(fp32 observation words + fp32 lens table), all accumulation and the solve in fp64 (BASELINE configs[4]'s arithmetic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the full LM solve after the timed sweeps (profiling runs: only sweep kernels in the trace)")
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
@@ -160,7 +166,20 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     spec = scene.baseline_spec(args.workload)
-    sc = scene.make_scene(spec)
+    use_web = args.lens_selection == "web" or (args.lens_selection == "auto" and args.workload.endswith("_web"))
+    selector = None
+    if use_web:
+        # which micro lenses see an image point: the reference's walk over the nearest lens and the epipolar web
+        # (src/CameraCalibration.cpp:661-752), run by this library's port of projectPointsToRawImage on the GPU
+        from lifcal_amd.mla import MicroLensGrid
+        grid = MicroLensGrid(spec.raw_width, spec.raw_height, spec.lens_diameter, spec.lens_base_y, spec.grid_rotation, spec.grid_offset, True, device=local_rank)
+
+        def selector(img_x, img_y, img_vd, img_fr, img_pt, scale):
+            o = grid.projectPointsToRawImage(img_x, img_y, img_vd, int(scale), fr=img_fr, pt=img_pt)
+            return o.src, o.mcx, o.mcy
+    sc = scene.make_scene(spec, lens_selector=selector)
+    if use_web:
+        grid.close()
     strong = args.scaling == "strong" and world > 1
     pa = tiled_problem(sc, world) if (world > 1 and not strong) else capi.ProblemArrays.from_scene(sc)
     n_obs_total = int(pa.struct.n_obs)
@@ -168,6 +187,7 @@ def main():
     o.device = local_rank
     o.rank = rank
     o.world_size = world
+    o.precision = args.precision
     t_create = time.perf_counter()
     ba = BundleAdjustment(pa, o)
     t_create = time.perf_counter() - t_create   # planner (host) + upload: once per problem, outside the metric
@@ -297,8 +317,9 @@ def main():
         n_loc = info.n_obs_local
         n_red = 17 + 6 * F_tot
         p_loc = info.n_points_local if strong else spec.n_points   # per-rank share of the algorithmic bytes (rank 0's shard)
-        b_kernel = accumulate_kernel_bytes(n_loc, p_loc, spec.n_frames)
-        b_sweep = algorithmic_bytes(n_loc, p_loc, spec.n_frames, 17 + 6 * spec.n_frames)
+        b_obs = 24 if args.precision == 1 else 40   # SURVEY.md 8(d); the fp32 stream this library reads is 12 B per observation (du, dv, lens index)
+        b_kernel = accumulate_kernel_bytes(n_loc, p_loc, spec.n_frames, b_obs)
+        b_sweep = algorithmic_bytes(n_loc, p_loc, spec.n_frames, 17 + 6 * spec.n_frames, b_obs)
         t_kernel = prof.ms_accumulate * 1e-3
         t_total = prof.ms_total * 1e-3
         achieved = b_kernel / t_kernel / 1e9
@@ -309,8 +330,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {F_tot} frames, {P_tot} points, {n_obs_total} micro-image observations, "
+            "dtype": "f64" if args.precision == 0 else "f32 residual+Jacobian / f64 accumulate+solve", "data": "synthetic",
+            "config": {"lens_selection": "reference generator (lifcal_mla_project)" if use_web else "K-nearest stand-in",
+                       "workload": f"{args.workload}: {F_tot} frames, {P_tot} points, {n_obs_total} micro-image observations, "
                                    f"window {spec.window}, config {spec.config:#x} (2 radial + tangential, mlCenterAdj, Cauchy(0.5), refine poses+points)",
                        "obs_per_gpu": n_loc, "n_reduced": n_red, "sharding": "by 3D point" if world > 1 else "single GPU", "comm": comm_used},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (residual+Jacobian+block accumulation)",

@@ -115,7 +115,9 @@ typedef struct lifcal_ba_options {
   double loss_scale;            /* 0.5: CauchyLoss(0.5) (:892) */
   int32_t max_iterations;       /* 200 (:960) */
   int32_t jacobi_scaling;       /* 1 */
-  int32_t precision;            /* 0: fp64 everywhere; 1 (fp32 residual/Jacobian, fp64 accumulation): NOT YET IMPLEMENTED, create() rejects it */
+  int32_t precision;            /* 0: fp64 everywhere; 1: residual and Jacobian of an observation evaluated in fp32 (observation stored relative to its
+                                   micro-lens centre, fp32 lens table: 12 B per observation in the sweep's stream), every accumulation, the
+                                   elimination and the solve in fp64; accept/reject decisions use fp64 costs (BASELINE configs[4])              */
   int32_t device;               /* HIP device ordinal */
   int32_t rank;                 /* this process' rank in the point-sharded job (0 if single GPU) */
   int32_t world_size;           /* number of ranks (1 if single GPU) */

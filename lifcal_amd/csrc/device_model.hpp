@@ -335,4 +335,123 @@ LIFCAL_DEV void obs_eval2(const CamConsts& c, const GroupConsts2& g, const doubl
   for (int j = 0; j < NC; ++j) { Jc[0][j] = dx[j] * s0; Jc[1][j] = dy[j] * s1; }
 }
 
+// ---- fp32 evaluation for options.precision = 1 (BASELINE configs[4]: "fp32 residuals / fp64 normal-eq accumulate") ----
+// Same chain as obs_eval2 in single precision.  What keeps fp32 adequate on ~1000-pixel coordinates:
+//   * the observation is stored relative to its micro-lens centre m (du = u - m.x, dv = v - m.y: a few pixels),
+//   * the lens table carries, per unique lens and computed in fp64, w = (a) c_u [mm] and the small pixel offset
+//     Lm = w / sp + c_raw - m (mlCenterAdj; 0 otherwise: c_d / sp + c_raw - m vanishes identically),
+//   so r = pMl / sp + Lm + Delta / sp - du is a sum of SMALL terms; the one cancellation left is inside pMl = gamma q - beta w
+//   (point direction against lens direction, ~40 : 1), i.e. ~1e-4 px of rounding on a 0.1 px noise floor.
+// Group constants are computed in fp64 (group_prepare2) and rounded once.
+struct CamF { float a, e, gamma, beta, isp0, isp1, sp0, sp1, k0, k1, p0, p1, loss_c; };
+LIFCAL_DEV CamF cam_to_float(const CamConsts& c) {
+  CamF f;
+  f.a = (float)c.a; f.e = (float)c.e; f.gamma = (float)c.gamma; f.beta = (float)c.beta;
+  f.isp0 = (float)c.isp[0]; f.isp1 = (float)c.isp[1]; f.sp0 = (float)c.sp[0]; f.sp1 = (float)c.sp[1];
+  f.k0 = (float)c.k[0]; f.k1 = (float)c.k[1]; f.p0 = (float)c.p[0]; f.p1 = (float)c.p[1]; f.loss_c = (float)c.loss_c;
+  return f;
+}
+struct GroupConsts2F { float X, Y, iZq, gz, kq[3], kc[3], gl; };
+template <bool ADJ>
+LIFCAL_DEV void group_prepare2f(const CamConsts& c, double X, double Y, double Z, GroupConsts2F& g) {
+  GroupConsts2 d; group_prepare2<ADJ>(c, X, Y, Z, d);
+  g.X = (float)d.X; g.Y = (float)d.Y; g.iZq = (float)d.iZq; g.gz = (float)d.gz; g.gl = (float)d.gl;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { g.kq[i] = (float)d.kq[i]; g.kc[i] = (float)(ADJ ? d.kc[i] / c.a : d.kc[i]); }   // multiplies w = a c_u instead of c_u
+}
+
+template <int NR, bool TAN>
+struct DistortionF {
+  float dx, dy, A00, A01, A10, A11, r2, r4;
+  LIFCAL_DEV void eval(float x, float y, const CamF& c) {
+    r2 = x * x + y * y; r4 = r2 * r2;
+    float g = 0.f, gp = 0.f;
+    if (NR >= 1) { g = c.k0 * r2; gp = c.k0; }
+    if (NR >= 2) { g += c.k1 * r4; gp += 2.f * c.k1 * r2; }
+    dx = x * g; dy = y * g;
+    const float xy2 = 2.f * x * y * gp; A00 = g + 2.f * x * x * gp; A01 = xy2; A10 = xy2; A11 = g + 2.f * y * y * gp;
+    if (TAN) {
+      dx += c.p0 * (r2 + 2.f * x * x) + 2.f * c.p1 * x * y;
+      dy += c.p1 * (r2 + 2.f * y * y) + 2.f * c.p0 * x * y;
+      A00 += 6.f * c.p0 * x + 2.f * c.p1 * y; A01 += 2.f * c.p0 * y + 2.f * c.p1 * x;
+      A10 += 2.f * c.p1 * x + 2.f * c.p0 * y; A11 += 6.f * c.p1 * y + 2.f * c.p0 * x;
+    }
+  }
+  LIFCAL_DEV void explicit_partial(int a, float x, float y, float& ex, float& ey) const {
+    ex = 0.f; ey = 0.f;
+    if (NR >= 1 && a == 2) { ex = x * r2; ey = y * r2; }
+    if (NR >= 2 && a == 3) { ex = x * r4; ey = y * r4; }
+    if (TAN && a == 2 + NR) { ex = r2 + 2.f * x * x; ey = 2.f * x * y; }
+    if (TAN && a == 3 + NR) { ex = 2.f * x * y; ey = r2 + 2.f * y * y; }
+  }
+};
+
+// fp32 lens-table row (16 floats): [0,1] w = (a) c_u [mm], [2,3] Lm [px], [4+2l, 5+2l] d c_u / d lens-parameter l (as the fp64 row)
+// r, Jq, Jc come back multiplied by sqrt(rho') when robust; arg = 1 + s/b (robust) or s (not robust), as obs_eval2
+template <int NR, bool TAN, bool ADJ>
+LIFCAL_DEV void obs_eval2f(const CamF& c, const GroupConsts2F& g, const float* __restrict__ L, float du, float dv, bool robust,
+                           float r[2], float Jq[2][3], float Jc[2][5 + NR + (TAN ? 2 : 0)], float& arg) {
+  constexpr int NA = 2 + NR + (TAN ? 2 : 0);
+  constexpr int NC = 3 + NA;
+  const float wx = L[0], wy = L[1];
+  const float qx = (g.X + wx * c.e) * g.iZq, qy = (g.Y + wy * c.e) * g.iZq;
+  const float mlx = c.gamma * qx - c.beta * wx, mly = c.gamma * qy - c.beta * wy;
+  float dx[NC], dy[NC];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { dx[i] = qx * g.kq[i] + wx * g.kc[i]; dy[i] = qy * g.kq[i] + wy * g.kc[i]; }
+#pragma unroll
+  for (int a = 0; a < NA; ++a) { dx[3 + a] = g.gl * L[4 + 2 * a]; dy[3 + a] = g.gl * L[5 + 2 * a]; }
+  const float qxZ = -g.gz * qx, qyZ = -g.gz * qy;
+  float j00, j01, j02, j10, j11, j12;
+  float r0 = mlx * c.isp0 - du, r1 = mly * c.isp1 - dv;
+  if (ADJ) {
+    r0 += L[2]; r1 += L[3];
+    if (NR > 0 || TAN) {
+      const float px = mlx + wx, py = mly + wy;
+      DistortionF<NR, TAN> d; d.eval(px, py, c);
+      const float b00 = 1.f + d.A00, b01 = d.A01, b10 = d.A10, b11 = 1.f + d.A11;
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        float ex = 0.f, ey = 0.f;
+        if (i >= 3) d.explicit_partial(i - 3, px, py, ex, ey);
+        const float nx = b00 * dx[i] + b01 * dy[i] + ex, ny = b10 * dx[i] + b11 * dy[i] + ey;
+        dx[i] = nx; dy[i] = ny;
+      }
+      j00 = b00 * g.gz; j01 = b01 * g.gz; j02 = b00 * qxZ + b01 * qyZ;
+      j10 = b10 * g.gz; j11 = b11 * g.gz; j12 = b10 * qxZ + b11 * qyZ;
+      r0 += d.dx * c.isp0; r1 += d.dy * c.isp1;
+    } else {
+      j00 = g.gz; j01 = 0.f; j02 = qxZ; j10 = 0.f; j11 = g.gz; j12 = qyZ;
+    }
+    dx[3] += c.sp0; dy[4] += c.sp1;
+  } else {
+    j00 = g.gz; j01 = 0.f; j02 = qxZ; j10 = 0.f; j11 = g.gz; j12 = qyZ;
+  }
+  r[0] = r0; r[1] = r1;
+  const float sq = r0 * r0 + r1 * r1;
+  float s0 = c.isp0, s1 = c.isp1;
+  if (robust) {
+    arg = 1.f + sq * c.loss_c;
+    const float sc = rsqrtf(arg);
+    r[0] *= sc; r[1] *= sc; s0 *= sc; s1 *= sc;
+  } else {
+    arg = sq;
+  }
+  Jq[0][0] = j00 * s0; Jq[0][1] = j01 * s0; Jq[0][2] = j02 * s0;
+  Jq[1][0] = j10 * s1; Jq[1][1] = j11 * s1; Jq[1][2] = j12 * s1;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) { Jc[0][j] = dx[j] * s0; Jc[1][j] = dy[j] * s1; }
+}
+
+// the fp32 lens-table row from the fp64 one (k_tables)
+template <bool ADJ>
+LIFCAL_DEV void lens_row_to_float(const CamConsts& c, const double* row, float* out) {
+  const double wx = ADJ ? row[2] * c.a : row[2], wy = ADJ ? row[3] * c.a : row[3];
+  out[0] = (float)wx; out[1] = (float)wy;
+  out[2] = ADJ ? (float)(wx * c.isp[0] + c.craw[0] - row[0]) : 0.f;
+  out[3] = ADJ ? (float)(wy * c.isp[1] + c.craw[1] - row[1]) : 0.f;
+#pragma unroll
+  for (int k = 4; k < LENS_STRIDE; ++k) out[k] = (float)row[k];
+}
+
 }  // namespace lifcal

@@ -21,6 +21,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "../../include/lifcal_ba.h"
 #include "device_model.hpp"
 
@@ -65,6 +67,8 @@ struct Dev {
   uint32_t n_blocks, v2_nfmax, n_special;
   const uint32_t *blk_pass0, *blk_flo, *blk_nf, *pass_pt0, *pass_np, *pass_gid0, *pass_ng, *v2_points, *v2_ptinfo, *v2_slot, *v2_tile_row0, *v2_lens, *v2f_pt, *v2_passpt, *v2_gidx;
   const double *v2_u, *v2_v;
+  const float *v2_du, *v2_dv;    // options.precision = 1: observation relative to its micro-lens centre (u - mcx, v - mcy), fp32
+  float* ltf;                    // options.precision = 1: fp32 lens table of the CURRENT point (see lens_row_to_float)
   const uint32_t* special_owned;
   // constraints
   const uint32_t *c_i, *c_j, *my_cons, *pt_cons0, *pt_cons_list; const double *c_dist, *c_sigma;
@@ -130,7 +134,8 @@ __global__ void k_lenses(const CamConsts* camc, const double* lens_xy, double* l
 // dependency on another kernel), lens table, frame table, and zero-filling of the accumulation buffers
 template <int NR, bool TAN>
 __global__ __launch_bounds__(256) void k_tables(Dev d, const double* cam, const double* views, CamConsts* camc_out, double* ft, double* lt,
-                                                const double* lens_xy, int want_tangents, int fold, double* zero0, uint32_t n_zero0, double* zero1, uint32_t n_zero1) {
+                                                const double* lens_xy, int want_tangents, int fold, double* zero0, uint32_t n_zero0, double* zero1, uint32_t n_zero1,
+                                                float* ltf /* fp32 lens table (options.precision = 1) or null */) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
   CamConsts c;
   cam_prepare(cam, d.spx, d.spy, fold ? d.scale : (double)(float)d.scale, (int)d.n_radial, d.tangential != 0, d.fixed_mask, d.loss_scale, fold != 0, c);
@@ -142,6 +147,12 @@ __global__ __launch_bounds__(256) void k_tables(Dev d, const double* cam, const 
     lens_eval<NR, TAN>(c, lens_xy[2 * (size_t)t], lens_xy[2 * (size_t)t + 1], want_tangents != 0, o);
 #pragma unroll
     for (int k = 0; k < LENS_STRIDE; ++k) lt[(size_t)t * LENS_STRIDE + k] = o[k];
+    if (ltf) {
+      float of[LENS_STRIDE];
+      if (d.adj) lens_row_to_float<true>(c, o, of); else lens_row_to_float<false>(c, o, of);
+#pragma unroll
+      for (int k = 0; k < LENS_STRIDE; ++k) ltf[(size_t)t * LENS_STRIDE + k] = of[k];
+    }
   }
   if (t < d.F) {
     double o[FRAME_STRIDE]; frame_eval(views + 6 * (size_t)t, o);

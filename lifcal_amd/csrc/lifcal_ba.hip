@@ -27,6 +27,10 @@
 
 using namespace lifcal;
 
+#ifndef LIFCAL_DEFAULT_SWEEP_WAVES
+#define LIFCAL_DEFAULT_SWEEP_WAVES 4
+#endif
+
 namespace {
 
 thread_local std::string g_last_error;
@@ -81,6 +85,7 @@ struct lifcal_ba_handle {
   double* red_block = nullptr; size_t red_count = 0;
   size_t v2_lds_bytes = 0;
   bool use_sweep3 = true;        // wave-specialised LDS-window kernel (LIFCAL_SWEEP_KERNEL=2 selects k_sweep2)
+  int sweep_waves = 4;           // k_sweep3: waves per role, 4 (512 threads, 256-lane passes) or 2 (256 threads, 128-lane passes, two workgroups per CU)
   TileSet ts1{}, ts2{};   // v1 tiles, v2 tiles (flat view)
   double* partial = nullptr;     // 4 doubles + 1 cand cost (all-reduced)
   double* hdiag_tmp = nullptr;
@@ -188,11 +193,11 @@ uint32_t sweep_grid(const lifcal_ba_handle* h) {
 
 // tables for a parameter set (camera constants, frames, lenses) + zero-fill of up to two buffers, ONE launch
 int launch_tables(lifcal_ba_handle* h, const double* cam, const double* views, CamConsts* camc, double* ft, double* lt, bool tangents, bool fold,
-                  double* zero0 = nullptr, size_t n_zero0 = 0, double* zero1 = nullptr, size_t n_zero1 = 0) {
+                  double* zero0 = nullptr, size_t n_zero0 = 0, double* zero1 = nullptr, size_t n_zero1 = 0, float* ltf = nullptr) {
   const Dev& d = h->d;
   const uint32_t work = std::max<uint32_t>(std::max(d.n_lenses, d.F), (uint32_t)std::min<size_t>((n_zero0 + n_zero1 + 7) / 8, 1u << 20));
   const uint32_t grid = std::max(1u, (work + 255) / 256);
-#define CALL_TABLES(NR, TAN) hipLaunchKernelGGL((k_tables<NR, TAN>), dim3(grid), dim3(256), 0, h->stream, d, cam, views, camc, ft, lt, (const double*)h->lens_xy, tangents ? 1 : 0, fold ? 1 : 0, zero0, (uint32_t)n_zero0, zero1, (uint32_t)n_zero1)
+#define CALL_TABLES(NR, TAN) hipLaunchKernelGGL((k_tables<NR, TAN>), dim3(grid), dim3(256), 0, h->stream, d, cam, views, camc, ft, lt, (const double*)h->lens_xy, tangents ? 1 : 0, fold ? 1 : 0, zero0, (uint32_t)n_zero0, zero1, (uint32_t)n_zero1, ltf)
   DISPATCH_LENS(h, CALL_TABLES);
 #undef CALL_TABLES
   HIP_TRY(hipGetLastError());
@@ -207,8 +212,13 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
   if (mode == 0 && h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(1), h->stream));
   if (d.n_blocks) {   // regular points: LDS-window kernel, one workgroup per block
 #define CALL_SWEEP2(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep2<NR, TAN, ADJ>), dim3(d.n_blocks), dim3(256), h->v2_lds_bytes, h->stream, d, radius, mode)
-#define CALL_SWEEP3(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep3<NR, TAN, ADJ>), dim3(d.n_blocks), dim3(512), h->v2_lds_bytes, h->stream, d, radius, mode)
-    if (h->use_sweep3) DISPATCH_CFG(h, CALL_SWEEP3); else DISPATCH_CFG(h, CALL_SWEEP2);
+#define CALL_SWEEP3(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep3<NR, TAN, ADJ, 4>), dim3(d.n_blocks), dim3(512), h->v2_lds_bytes, h->stream, d, radius, mode)
+#define CALL_SWEEP3F(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep3<NR, TAN, ADJ, 4, float>), dim3(d.n_blocks), dim3(512), h->v2_lds_bytes, h->stream, d, radius, mode)
+#define CALL_SWEEP3H(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep3<NR, TAN, ADJ, 2>), dim3(d.n_blocks), dim3(256), h->v2_lds_bytes, h->stream, d, radius, mode)
+    if (h->opt.precision == 1) DISPATCH_CFG(h, CALL_SWEEP3F);
+    else if (h->use_sweep3 && h->sweep_waves == 2) DISPATCH_CFG(h, CALL_SWEEP3H); else if (h->use_sweep3) DISPATCH_CFG(h, CALL_SWEEP3); else DISPATCH_CFG(h, CALL_SWEEP2);
+#undef CALL_SWEEP3H
+#undef CALL_SWEEP3F
 #undef CALL_SWEEP3
 #undef CALL_SWEEP2
   }
@@ -229,7 +239,7 @@ int launch_sweep(lifcal_ba_handle* h, double radius) {
   Dev& d = h->d;
   if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));
   // the table kernel also zero-fills the reduced block and the step scalars
-  if (int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true, h->red_block, h->red_count, d.step, ST_N)) return rc;
+  if (int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true, h->red_block, h->red_count, d.step, ST_N, d.ltf)) return rc;
   bool zeroed = true;
   if (!h->sigma_valid) {
     // ceres fixes the Jacobi scaling at iteration 0 from the column norms of the (loss-corrected) Jacobian:
@@ -308,6 +318,29 @@ int launch_candidate(lifcal_ba_handle* h) {
   return 0;
 }
 
+// fp64 cost of the CURRENT point through the value-only kernel (options.precision = 1: the LM decisions compare costs of one
+// arithmetic — current and candidate both from k_cost — while the sweep's own cost comes from its fp32 residuals)
+int cost64_current(lifcal_ba_handle* h, double* cost) {
+  Dev& d = h->d;
+  HIP_TRY(hipMemsetAsync(h->partial, 0, 8 * sizeof(double), h->stream));
+  const double* pts_eval = d.pts;
+  for (const TileSet* ts : {&h->ts1, &h->ts2}) {
+    if (!ts->n_tiles) continue;
+    const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 1024u));
+#define CALL_COST0(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)d.camc, (const double*)d.ft, (const double*)d.lt, pts_eval, h->partial + 4)
+    DISPATCH_CFG(h, CALL_COST0);
+#undef CALL_COST0
+  }
+  if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
+  HIP_TRY(hipGetLastError());
+  if (int rc = do_allreduce(h, h->partial, 8)) return rc;
+  double hp[8];
+  HIP_TRY(hipMemcpyAsync(hp, h->partial, sizeof(hp), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  *cost = hp[4];
+  return 0;
+}
+
 // ---- Armijo line search (bounded problems) ---------------------------------------------------------------------
 // candidate = Plus(x, t delta); returns |x - candidate|^2 and |x|^2 in ls_buf
 int launch_apply_step(lifcal_ba_handle* h, double t) {
@@ -326,7 +359,7 @@ int eval_trial(lifcal_ba_handle* h, double t, double radius, LsSample* smp) {
   if (int rc = launch_apply_step(h, t)) return rc;
   auto swap_all = [&]() { std::swap(d.cam, d.cam_c); std::swap(d.views, d.views_c); if (d.use_points) std::swap(d.pts, d.pts_c); };
   swap_all();
-  int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true, h->red_block, h->red_count, d.step, ST_N);
+  int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true, h->red_block, h->red_count, d.step, ST_N, d.ltf);
   if (!rc) rc = launch_blocks(h, radius, 0, true);
   if (!rc && d.use_points && d.n_special) { hipLaunchKernelGGL(k_schur, dim3((d.n_special + 3) / 4), dim3(256), 0, h->stream, d, radius); }
   if (!rc) rc = do_allreduce(h, h->red_block, h->red_count);
@@ -495,16 +528,25 @@ int lifcal_init_plenoptic(const lifcal_init_problem* p, int32_t device, lifcal_i
   return 0;
 }
 
+// k_sweep3's waves per role: LIFCAL_SWEEP_WAVES = 2 | 4 (k_sweep2 always works on 256-lane passes)
+static int sweep_waves_from_env(bool sweep3) {
+  if (!sweep3) return 4;
+  const char* e = getenv("LIFCAL_SWEEP_WAVES");
+  const int w = e ? atoi(e) : LIFCAL_DEFAULT_SWEEP_WAVES;
+  return w == 2 ? 2 : 4;
+}
+
 int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size, lifcal_ba_plan_info* info,
                    uint32_t* obs_order, uint32_t* point_owner) {
   Plan pl;
   // the same layout lifcal_ba_create builds by default (lanes in frame order for the wave-specialised sweep kernel)
   const bool frame_order = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
-  if (int rc = build_plan(p, rank, world_size, &pl, true, 256, UINT32_MAX, frame_order)) return rc;
+  const int waves = sweep_waves_from_env(frame_order);
+  if (int rc = build_plan(p, rank, world_size, &pl, true, waves == 2 ? 512u : 256u, UINT32_MAX, frame_order, waves == 2 ? 128u : 256u)) return rc;
   if (info) {
     info->n_groups = pl.n_pairs; info->n_tiles = pl.n_tiles; info->n_lenses = pl.n_lenses; info->n_promoted = pl.Q;
     info->n_reduced = pl.n_red_canon; info->max_group_obs = pl.max_group_obs; info->n_chunks = pl.n_blocks; info->max_window_frames = pl.bw + 1;
-    info->n_tiles = pl.n_tiles + 4 * pl.n_passes;
+    info->n_tiles = pl.n_tiles + pl.pass_tiles() * pl.n_passes;
   }
   if (obs_order) { for (uint32_t i = 0; i < p->n_obs; ++i) obs_order[i] = UINT32_MAX; for (size_t s = 0; s < pl.obs_order.size(); ++s) obs_order[s] = pl.obs_order[s]; }
   if (point_owner) for (uint32_t q = 0; q < p->n_points; ++q) point_owner[q] = (uint32_t)pl.owner[q];
@@ -516,10 +558,10 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   *out = nullptr;
   lifcal_ba_options opt; if (o) opt = *o; else lifcal_ba_default_options(&opt);
   if (opt.world_size < 1 || opt.world_size > 64 || opt.rank < 0 || opt.rank >= opt.world_size) return LIFCAL_BA_ERR_INVALID_ARG;
-  if (opt.precision != 0 || opt.deterministic != 0) {
-    // declared in the ABI for BASELINE configs[4] (fp32 residual/Jacobian) and for ordered reductions; neither exists yet,
-    // and silently running the fp64 / atomic path instead would misreport what was measured
-    g_last_error = "options.precision = 1 and options.deterministic = 1 are not implemented in this version";
+  if ((opt.precision != 0 && opt.precision != 1) || opt.deterministic != 0) {
+    // deterministic = 1 (ordered reductions) is declared in the ABI but does not exist yet; silently running the atomic path
+    // instead would misreport what was measured
+    g_last_error = "options.precision must be 0 or 1; options.deterministic = 1 is not implemented in this version";
     return LIFCAL_BA_ERR_INVALID_ARG;
   }
   lifcal_ba_handle* h = new (std::nothrow) lifcal_ba_handle();
@@ -528,15 +570,21 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   // tuning / A-B knobs (not part of the ABI): LIFCAL_DISABLE_V2=1 forces the global-atomic kernels,
   // LIFCAL_V2_BLOCKS sets the number of workgroups the LDS-window sweep is cut into (default: one per CU)
   const bool enable_v2 = getenv("LIFCAL_DISABLE_V2") == nullptr;
-  const uint32_t v2_blocks = getenv("LIFCAL_V2_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("LIFCAL_V2_BLOCKS"))) : 256u;
+  // the wave-specialised kernel wants the lanes of a pass sorted by frame, k_sweep2 (LIFCAL_SWEEP_KERNEL=2) by point
+  h->use_sweep3 = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
+  h->sweep_waves = sweep_waves_from_env(h->use_sweep3);
+  if (opt.precision == 1) {
+    // fp32 residual / Jacobian evaluation exists in the wave-specialised kernel with four waves per role only
+    if (!h->use_sweep3) { g_last_error = "options.precision = 1 needs k_sweep3 (unset LIFCAL_SWEEP_KERNEL)"; delete h; return LIFCAL_BA_ERR_INVALID_ARG; }
+    h->sweep_waves = 4;
+  }
+  const uint32_t v2_blocks = getenv("LIFCAL_V2_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("LIFCAL_V2_BLOCKS"))) : (h->sweep_waves == 2 ? 512u : 256u);
   // LIFCAL_GROUP_SPLIT: observations per lane above which a (point, frame) group is cut into several lanes
   // (0 = never; default: chosen per block by the planner's cost model)
   const uint32_t split_obs = getenv("LIFCAL_GROUP_SPLIT") ? (uint32_t)std::max(0, atoi(getenv("LIFCAL_GROUP_SPLIT"))) : UINT32_MAX;
-  // the wave-specialised kernel wants the lanes of a pass sorted by frame, k_sweep2 (LIFCAL_SWEEP_KERNEL=2) by point
-  h->use_sweep3 = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
   h->trace = getenv("LIFCAL_TRACE") != nullptr;
   PlanClock cclk;
-  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs, h->use_sweep3);
+  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs, h->use_sweep3, h->sweep_waves == 2 ? 128u : 256u, opt.precision == 1);
   if (rc) { delete h; return rc; }
   cclk.lap("create: plan");
   h->prob = *p;
@@ -585,23 +633,26 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
     U(t, L.pass_pt0); d.pass_pt0 = t; U(t, L.pass_np); d.pass_np = t; U(t, L.pass_gid0); d.pass_gid0 = t; U(t, L.pass_ng); d.pass_ng = t;
     U(t, L.v2_points); d.v2_points = t; U(t, L.v2_ptinfo); d.v2_ptinfo = t; U(t, L.v2_passpt); d.v2_passpt = t; U(t, L.v2_gidx); d.v2_gidx = t; U(t, L.v2_slot); d.v2_slot = t; U(t, L.v2_tile_row0); d.v2_tile_row0 = t; U(t, L.v2_lens); d.v2_lens = t; }
   { double* t; U(t, L.v2_u); d.v2_u = t; U(t, L.v2_v); d.v2_v = t; }
+  if (opt.precision == 1) { float* t; U(t, L.v2_du); d.v2_du = t; U(t, L.v2_dv); d.v2_dv = t; A(d.ltf, (size_t)d.n_lenses * LENS_STRIDE); }
   { uint32_t *a, *b, *c; U(a, L.v2f_pt); U(b, L.v2f_fr); U(c, L.v2f_cnt);
     d.v2f_pt = a;
-    h->ts2 = TileSet{4 * L.n_passes, d.v2_tile_row0, a, b, c, d.v2_lens, d.v2_u, d.v2_v}; }
+    h->ts2 = TileSet{L.pass_tiles() * L.n_passes, d.v2_tile_row0, a, b, c, d.v2_lens, d.v2_u, d.v2_v}; }
   d.n_blocks = L.n_blocks; d.v2_nfmax = std::max(1u, L.max_block_nf); d.n_special = (uint32_t)L.special_owned.size();
   // the LDS-window kernels trust the plan: the dense Z matrix of every pass (rows rounded up to 8) must fit its LDS region
   for (uint32_t b = 0; b < L.n_blocks; ++b) {
     const uint32_t ncolp = ((6 * L.blk_nf[b] + (uint32_t)L.nc + 1) + 15u) & ~15u;
     for (uint32_t ps = L.blk_pass0[b]; ps < L.blk_pass0[b + 1]; ++ps)
-      if ((size_t)((3 * L.pass_np[ps] + 7u) & ~7u) * (ncolp + 2) > ZD_DOUBLES || L.pass_ng[ps] > Plan::PASS_GROUPS || L.pass_np[ps] > Plan::NP_MAX) {
+      if ((size_t)((3 * L.pass_np[ps] + 7u) & ~7u) * (ncolp + 2) > L.zd_doubles() || L.pass_ng[ps] > L.pass_lanes || L.pass_np[ps] > L.np_max()) {
         g_last_error = "internal: a planned pass does not fit the LDS window";
         return fail(LIFCAL_BA_ERR_INVALID_ARG);
       }
   }
-  h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax, h->use_sweep3).total * sizeof(double);
+  h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax, h->use_sweep3, L.pass_lanes).total * sizeof(double);
   if (d.n_blocks) {
 #define SET_LDS(NR, TAN, ADJ) do { if (hipFuncSetAttribute((const void*)k_sweep2<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
-    if (hipFuncSetAttribute((const void*)k_sweep3<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); } while (0)
+    if (hipFuncSetAttribute((const void*)k_sweep3<NR, TAN, ADJ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
+    if (hipFuncSetAttribute((const void*)k_sweep3<NR, TAN, ADJ, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
+    if (hipFuncSetAttribute((const void*)k_sweep3<NR, TAN, ADJ, 4, float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); } while (0)
     DISPATCH_CFG(h, SET_LDS);
 #undef SET_LDS
   }
@@ -735,7 +786,7 @@ int lifcal_ba_get_info(lifcal_ba_handle* h, lifcal_ba_info* out) {
   out->n_obs_local = h->plan.n_obs_local; out->n_points_local = (uint32_t)h->plan.owned_points.size();
   out->n_groups = h->plan.n_pairs; out->n_tiles = h->plan.n_tiles; out->n_lenses = h->plan.n_lenses;
   out->n_reduced = h->plan.n_red_canon; out->n_promoted = h->plan.Q; out->n_chunks = h->plan.n_blocks; out->max_window_frames = h->d.bw + 1;
-  out->n_tiles = h->plan.n_tiles + 4 * h->plan.n_passes;
+  out->n_tiles = h->plan.n_tiles + h->plan.pass_tiles() * h->plan.n_passes;
   out->device_bytes = h->bytes; out->stream = (void*)h->stream;
   return 0;
 }
@@ -846,6 +897,7 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
   double t0 = now_s();
   if (int rc = launch_sweep(h, radius)) return rc;
   if (int rc = read_sweep_scalars(h, &x_cost, &gmax, &bad)) return rc;
+  if (o.precision == 1) { if (int rc = cost64_current(h, &x_cost)) return rc; }
   s->seconds_sweep += now_s() - t0;
   if (!std::isfinite(x_cost)) { g_last_error = "non-finite cost at the initial point"; return LIFCAL_BA_ERR_NUMERIC; }
   s->initial_cost = x_cost;
@@ -968,6 +1020,7 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
       decrease_factor = 2.0;
       if (int rc = launch_sweep(h, radius)) return rc;
       if (int rc = read_sweep_scalars(h, &x_cost, &gmax, &bad)) return rc;
+      if (o.precision == 1) x_cost = cand_cost;   // the fp64 cost of the point just accepted (see cost64_current)
       s->seconds_sweep += now_s() - t0;
       system_ready = true; step_successful = true; ++s->successful_steps;
     } else {

@@ -86,8 +86,12 @@ struct Plan {
   std::vector<uint32_t> slot_gid;      // v1 path: gid of each slot
   // ---- v2 (LDS-window) path: regular points only -------------------------------------------------
   // block  = one workgroup: contiguous range of points whose frames fit a window of <= NF_MAX frames
-  // pass   = <= 256 groups / <= 64 points of a block (4 tiles, group g -> wave g%4, lane g/4)
+  // pass   = <= pass_lanes (256 or 128) lanes / <= pass_lanes / 4 points of a block, in tiles of 64 lanes
   static constexpr uint32_t NF_MAX = 20, NP_MAX = 64, PASS_GROUPS = 256, ZD_DOUBLES = 8192;
+  uint32_t pass_lanes = PASS_GROUPS;   // lanes per pass of this plan: 256 (four tiles) or 128 (two tiles, half the Z matrix: k_sweep3 with two waves per role)
+  uint32_t pass_tiles() const { return pass_lanes / 64; }
+  uint32_t zd_doubles() const { return pass_lanes >= 256 ? ZD_DOUBLES : ZD_DOUBLES / 2; }
+  uint32_t np_max() const { return pass_lanes / 4; }
   uint32_t n_blocks = 0, n_passes = 0, max_block_nf = 0;
   std::vector<uint8_t> pt_special;     // P: the point takes the v1 (global-atomic) kernels
   std::vector<uint32_t> rk_flo, rk_nfr;   // per rank: first frame and number of frames its points observe (identical on every rank)
@@ -103,6 +107,7 @@ struct Plan {
   std::vector<uint32_t> v2f_pt, v2f_fr, v2f_cnt;   // the same slots, flat (value-only kernels: cost, statistics)
   std::vector<uint32_t> v2_tile_row0;  // 4*n_passes+1
   ZeroVec<double> v2_u, v2_v; ZeroVec<uint32_t> v2_lens; std::vector<uint32_t> v2_src;
+  ZeroVec<float> v2_du, v2_dv;         // options.precision = 1 only: (u - mcx, v - mcy) of the same rows in fp32
   std::vector<uint32_t> special_owned; // owned points handled by the v1 kernels (promoted / constrained / oversized)
   uint32_t n_obs_v2 = 0;
   // lenses
@@ -167,12 +172,16 @@ struct PlanClock {
   }
 };
 
-inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl, bool enable_v2 = true, uint32_t target_blocks = 256, uint32_t split_obs = UINT32_MAX, bool frame_order = false) {
+inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl, bool enable_v2 = true, uint32_t target_blocks = 256, uint32_t split_obs = UINT32_MAX, bool frame_order = false,
+                      uint32_t pass_lanes = Plan::PASS_GROUPS, bool want_f32 = false) {
   PlanClock clk;
   if (int rc = plan_validate(p)) return rc;
   clk.lap("validate");
   if (world < 1 || rank < 0 || rank >= world) return LIFCAL_BA_ERR_INVALID_ARG;
   Plan& L = *pl;
+  if (pass_lanes != 128 && pass_lanes != 256) return LIFCAL_BA_ERR_INVALID_ARG;
+  L.pass_lanes = pass_lanes;
+  const uint32_t PL = L.pass_lanes, PT = L.pass_tiles();
   L.F = p->n_frames; L.P = p->n_points; L.N = p->n_obs; L.M = p->n_constraints;
   L.rank = rank; L.world = world; L.config = p->config;
   L.n_radial = p->config & 3; L.tangential = (p->config & LIFCAL_BA_CFG_TANGENTIAL) != 0;
@@ -334,7 +343,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   for (uint32_t q = 0; q < L.P; ++q) {
     if (!cnt[q]) continue;
     if (!enable_v2 || !L.use_points) special[q] = 1;                    // camera-only / pose-only arities: v1 kernels
-    if (last[q] - first[q] + 1 > Plan::NF_MAX || L.pt_nslots[q] > Plan::PASS_GROUPS) special[q] = 1;
+    if (last[q] - first[q] + 1 > Plan::NF_MAX || L.pt_nslots[q] > PL) special[q] = 1;
   }
   for (const Group& G : groups) if (G.n > 255) special[G.pt] = 1;   // the v2 slot word keeps the group size in 8 bits
 
@@ -368,7 +377,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   auto block_np_cap = [&](size_t b) {
     // the dense Z matrix of a pass (3 np rows x padded window columns) must fit its LDS budget
     const uint32_t ncolp = ((6 * L.blk_nf[b] + (uint32_t)L.nc + 1) + 15u) & ~15u;
-    return std::max(1u, std::min<uint32_t>(Plan::NP_MAX, ((Plan::ZD_DOUBLES / (ncolp + 2)) & ~7u) / 3));
+    return std::max(1u, std::min<uint32_t>(L.np_max(), ((L.zd_doubles() / (ncolp + 2)) & ~7u) / 3));
   };
 
   clk.lap("v2 blocks");
@@ -383,7 +392,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     std::vector<uint32_t> split_of(L.P, 0);   // 0 = leave the point's groups whole
     auto parts_of = [](uint32_t n, uint32_t T) { return T ? (n + T - 1) / T : 1u; };
     // cycles per observation step of a pass, per pass, per lane (LIFCAL_PLAN_COST="step,pass,lane" overrides: tuning aid)
-    double C_STEP = 4700.0, C_PASS = 21500.0, C_LANE = 65.0;
+    double C_STEP = 4700.0, C_PASS = (PL >= 256 ? 21500.0 : 13000.0), C_LANE = 65.0;
     if (const char* e = getenv("LIFCAL_PLAN_COST")) { double a, b2, c2; if (sscanf(e, "%lf,%lf,%lf", &a, &b2, &c2) == 3) { C_STEP = a; C_PASS = b2; C_LANE = c2; } }
     // blocks are independent (each writes split_of / pass_break of its own points only)
     plan_parallel_for(blk_begin.empty() ? 0u : (uint32_t)(blk_begin.size() - 1), 4, [&](uint32_t b) {
@@ -415,9 +424,9 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
         double best = 1e300;
         for (size_t t = 0; t < nT; ++t) {
           uint32_t ng = 0, st = 0; size_t e = i;
-          while (e < n && e - i < np_cap && ng + lanes[e * nT + t] <= Plan::PASS_GROUPS) { ng += lanes[e * nT + t]; st = std::max(st, steps[e * nT + t]); ++e; }
+          while (e < n && e - i < np_cap && ng + lanes[e * nT + t] <= PL) { ng += lanes[e * nT + t]; st = std::max(st, steps[e * nT + t]); ++e; }
           if (e == i) continue;                                                  // a single point too wide for this split size
-          if (Ts[t] != 0 && lanes[i * nT + t] > Plan::PASS_GROUPS / 4 && nT > 1) continue;   // keep several points per pass
+          if (Ts[t] != 0 && lanes[i * nT + t] > PL / 4 && nT > 1) continue;   // keep several points per pass
           const double c = C_STEP * st + C_PASS + C_LANE * ng + cost[e];
           if (c < best) { best = c; pick[i] = (uint32_t)t; nxt[i] = (uint32_t)e; }
         }
@@ -491,7 +500,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     while (a < j) {
       uint32_t ng = 0, np = 0; size_t e = a;
       // a pass covers one contiguous run of gids (a special point's groups in between end the pass)
-      while (e < j && np < np_cap && ng + L.pt_nslots[reg[e]] <= Plan::PASS_GROUPS && !(e > a && pass_break[reg[e]]) &&
+      while (e < j && np < np_cap && ng + L.pt_nslots[reg[e]] <= PL && !(e > a && pass_break[reg[e]]) &&
              (e == a || L.pt_slot0[reg[e]] == L.pt_slot0[reg[e - 1]] + L.pt_nslots[reg[e - 1]])) { ng += L.pt_nslots[reg[e]]; ++np; ++e; }
       L.pass_pt0.push_back((uint32_t)L.v2_points.size()); L.pass_np.push_back(np);
       L.pass_gid0.push_back(L.pt_slot0[reg[a]]); L.pass_ng.push_back(ng);
@@ -505,9 +514,9 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   L.v2_passpt.assign((size_t)L.n_passes * Plan::NP_MAX, 0);
   for (uint32_t ps = 0; ps < L.n_passes; ++ps)
     for (uint32_t k = 0; k < L.pass_np[ps]; ++k) L.v2_passpt[(size_t)ps * Plan::NP_MAX + k] = L.v2_points[L.pass_pt0[ps] + k];
-  L.v2_slot.assign((size_t)L.n_passes * 256, 0);
-  L.v2f_pt.assign((size_t)L.n_passes * 256, 0); L.v2f_fr.assign((size_t)L.n_passes * 256, 0); L.v2f_cnt.assign((size_t)L.n_passes * 256, 0);
-  L.v2_tile_row0.assign((size_t)L.n_passes * 4 + 1, 0);
+  L.v2_slot.assign((size_t)L.n_passes * PL, 0);
+  L.v2f_pt.assign((size_t)L.n_passes * PL, 0); L.v2f_fr.assign((size_t)L.n_passes * PL, 0); L.v2f_cnt.assign((size_t)L.n_passes * PL, 0);
+  L.v2_tile_row0.assign((size_t)L.n_passes * PT + 1, 0);
   {
     // a pass's groups are contiguous gids (regular points between two specials may be split by a special
     // point's groups, so walk the pass's points explicitly)
@@ -539,16 +548,18 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
         std::stable_sort(lanes[ps].begin(), lanes[ps].end(), [&](const LaneOf& x, const LaneOf& y) { return groups[x.gid].fr < groups[y.gid].fr; });
     });
   clk.lap("v2: lanes+sort");
-    auto slot_of = [&](uint32_t k, uint32_t& w, uint32_t& l) { if (frame_order) { w = k / 64; l = k % 64; } else { w = k % 4; l = k / 4; } };
+    auto slot_of = [&](uint32_t k, uint32_t& w, uint32_t& l) { if (frame_order) { w = k / 64; l = k % 64; } else { w = k % PT; l = k / PT; } };
     for (uint32_t ps = 0; ps < L.n_passes; ++ps) {
       uint32_t kmax[4] = {0, 0, 0, 0};
       for (uint32_t k = 0; k < lanes[ps].size(); ++k) { uint32_t w, l; slot_of(k, w, l); kmax[w] = std::max(kmax[w], groups[lanes[ps][k].gid].n); }
-      for (uint32_t w = 0; w < 4; ++w) L.v2_tile_row0[(size_t)ps * 4 + w + 1] = L.v2_tile_row0[(size_t)ps * 4 + w] + kmax[w];
+      for (uint32_t w = 0; w < PT; ++w) L.v2_tile_row0[(size_t)ps * PT + w + 1] = L.v2_tile_row0[(size_t)ps * PT + w] + kmax[w];
     }
-    const size_t rows = L.v2_tile_row0[(size_t)L.n_passes * 4];
+    const size_t rows = L.v2_tile_row0[(size_t)L.n_passes * PT];
     L.v2_u = ZeroVec<double>(); L.v2_v = ZeroVec<double>(); L.v2_lens = ZeroVec<uint32_t>();   // fresh storage: zero pages, untouched
     L.v2_u.resize(rows * 64); L.v2_v.resize(rows * 64); L.v2_lens.resize(rows * 64); L.v2_src.assign(rows * 64, UINT32_MAX);
-    L.v2_gidx.assign((size_t)L.n_passes * 256, 0);
+    L.v2_du = ZeroVec<float>(); L.v2_dv = ZeroVec<float>();
+    if (want_f32) { L.v2_du.resize(rows * 64); L.v2_dv.resize(rows * 64); }
+    L.v2_gidx.assign((size_t)L.n_passes * PL, 0);
   clk.lap("v2: rows+alloc");
     std::vector<uint32_t> pass_block(L.n_passes, 0);
     for (uint32_t b = 0; b < L.n_blocks; ++b) for (uint32_t ps = L.blk_pass0[b]; ps < L.blk_pass0[b + 1]; ++ps) pass_block[ps] = b;
@@ -563,14 +574,15 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
           uint32_t w, l; slot_of(k, w, l);
           const uint32_t lfl = G.fr - L.blk_flo[b];
           const uint32_t rep = std::min(255u, occ[w * (Plan::NF_MAX + 1) + lfl]++);
-          const size_t at_slot = (size_t)ps * 256 + w * 64 + l;
+          const size_t at_slot = (size_t)ps * PL + w * 64 + l;
           L.v2_slot[at_slot] = std::min(G.n, 255u) | (lfl << 8) | (lp << 16) | (rep << 24);
           L.v2f_pt[at_slot] = G.pt; L.v2f_fr[at_slot] = G.fr; L.v2f_cnt[at_slot] = G.n;
           L.v2_gidx[at_slot] = lanes[ps][k].gid;
           for (uint32_t j = 0; j < G.n; ++j) {
-            const size_t at = ((size_t)L.v2_tile_row0[(size_t)ps * 4 + w] + j) * 64 + l;
+            const size_t at = ((size_t)L.v2_tile_row0[(size_t)ps * PT + w] + j) * 64 + l;
             const uint32_t i = L.obs_order[G.s0 + j];
             L.v2_u[at] = p->u[i]; L.v2_v[at] = p->v[i]; L.v2_lens[at] = obs_lens[G.s0 + j]; L.v2_src[at] = i;
+            if (want_f32) { L.v2_du[at] = (float)(p->u[i] - p->mcx[i]); L.v2_dv[at] = (float)(p->v[i] - p->mcy[i]); }
           }
         }
         // the pass's gids must be one contiguous run for the W staging (true unless a special point sits inside)
@@ -594,6 +606,12 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     for (uint32_t c = 0; c < L.M; ++c) if (L.owner[L.c_i[c]] < 0) { L.owner[L.c_i[c]] = 0; if (rank == 0) L.owned_points.push_back(L.c_i[c]); }
   }
   clk.lap("constraints csr");
+  if (clk.on) {
+    uint64_t lanes = 0, steps = 0;
+    for (uint32_t ps = 0; ps < L.n_passes; ++ps) { lanes += L.pass_ng[ps]; for (uint32_t w = 0; w < PT; ++w) steps += L.v2_tile_row0[(size_t)ps * PT + w + 1] - L.v2_tile_row0[(size_t)ps * PT + w]; }
+    std::fprintf(stderr, "[plan] blocks %u passes %u (lanes/pass %u) max block frames %u, lanes %llu (%.1f per pass), tile steps %llu (%.2f per tile), obs %u\n", L.n_blocks, L.n_passes, PL,
+                 L.max_block_nf, (unsigned long long)lanes, L.n_passes ? (double)lanes / L.n_passes : 0.0, (unsigned long long)steps, L.n_passes ? (double)steps / (L.n_passes * PT) : 0.0, L.n_obs_v2);
+  }
   L.pt_special = special;
   L.special_owned.clear();
   for (uint32_t q : L.owned_points) if (special[q] || L.pt_nslots[q] == 0) { L.special_owned.push_back(q); L.pt_special[q] = 1; }

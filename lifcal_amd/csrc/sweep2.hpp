@@ -26,24 +26,29 @@ constexpr uint32_t FRV = 27 + 6 * NCMAX;   // frame-level values a group emits: 
 constexpr uint32_t LDS_LIMIT_DOUBLES = 160 * 1024 / 8;
 
 struct V2Lds {
-  uint32_t nfm, nrep, off_cp, off_cc, off_vec, off_fr, off_bt, off_slab, off_zd, off_misc, total;
+  uint32_t nfm, nrep, np_max, zd, off_cp, off_cc, off_vec, off_fr, off_bt, off_slab, off_zd, off_misc, total;
+  // LDS doubles of the dense Z matrix of one pass (and of the hand-off buffer that lives there during the observation loop)
+  __host__ __device__ static constexpr uint32_t zd_for(uint32_t pass_lanes) { return pass_lanes >= 256 ? ZD_DOUBLES : ZD_DOUBLES / 2; }
   // single_replica: k_sweep3 (lanes sorted by frame, frame-level values pre-summed over runs of lanes): one set of frame
-  // accumulators; the LDS this frees holds the accumulator threads' partial Schur tiles (16 doubles x 256 threads) when they fit
-  __host__ __device__ explicit V2Lds(uint32_t nfmax, bool single_replica = false) {
+  // accumulators; the LDS this frees holds the accumulator threads' partial Schur tiles (16 doubles x 256 threads) when they fit.
+  // pass_lanes: 256 (k_sweep2, k_sweep3 with four waves per role) or 128 (k_sweep3 with two waves per role: half the Z matrix,
+  // half the per-pass point slab, no partial tiles — the window of a 12-frame block then takes ~75 KiB, two workgroups per CU)
+  __host__ __device__ explicit V2Lds(uint32_t nfmax, bool single_replica = false, uint32_t pass_lanes = 256) {
     nfm = nfmax;
+    zd = zd_for(pass_lanes); np_max = pass_lanes / 4;
     const uint32_t npp = nfm * (nfm + 1) / 2;
     off_cp = npp * 36; off_cc = off_cp + NCMAX * 6 * nfm; off_vec = off_cc + 48;
     off_fr = off_vec + 3 * (6 * nfm + NCMAX + 3);
     off_fr = (off_fr + 1) & ~1u;
     // replicated frame accumulators [value][rep][frame]: as many replicas (<= 8) as the 160 KiB LDS allows
-    const uint32_t fixed = off_fr + 64 * 12 + ZD_DOUBLES + 8 + 32 + 64;
+    const uint32_t fixed = off_fr + np_max * 12 + zd + 8 + 32 + 64;
     uint32_t r = (LDS_LIMIT_DOUBLES - fixed) / (FRV * nfm);
     nrep = single_replica ? 1u : (r < 1 ? 1 : (r > 8 ? 8 : r));
     off_bt = off_fr + nrep * FRV * nfm;
     off_bt = (off_bt + 1) & ~1u;
-    const bool bt = single_replica && (off_bt + 16 * 256 + 64 * 12 + ZD_DOUBLES + 8 + 32 + 64 <= LDS_LIMIT_DOUBLES);
+    const bool bt = single_replica && pass_lanes >= 256 && (off_bt + 16 * 256 + np_max * 12 + zd + 8 + 32 + 64 <= LDS_LIMIT_DOUBLES);
     off_slab = off_bt + (bt ? 16 * 256 : 0);
-    off_zd = off_slab + 64 * 12; off_misc = off_zd + ZD_DOUBLES; total = off_misc + 8 + 32 + 64;   // misc(8) | point ids (64 u32) | column info (<= 256 u16)
+    off_zd = off_slab + np_max * 12; off_misc = off_zd + zd; total = off_misc + 8 + 32 + 64;   // misc(8) | point ids (64 u32) | column info (<= 256 u16)
   }
   __host__ __device__ bool has_bt() const { return off_slab != off_bt; }
 };

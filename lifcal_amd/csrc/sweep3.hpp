@@ -18,14 +18,22 @@
 
 namespace lifcal {
 
-template <int NR, bool TAN, bool ADJ>
-__global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) {
+// WR = waves per role: 4 (512 threads, passes of 256 lanes, one workgroup per CU) or 2 (256 threads, passes of 128 lanes, an LDS
+// window under 80 KiB: TWO workgroups per CU, out of step with each other, so that one's latency-bound phases — pass top,
+// the single-wave factor phase, LDS-atomic emission — run under the other's observation loop).
+// ET = evaluation type: double, or float for options.precision = 1 (residual and Jacobian of an observation in fp32 from fp32
+// observation words and the fp32 lens table, hand-off in fp32; every accumulator and everything behind the loop stays fp64).
+template <int NR, bool TAN, bool ADJ, int WR, class ET = double>
+__global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, int mode) {
+  constexpr bool F32 = sizeof(ET) == 4;
   constexpr int NC = 5 + NR + (TAN ? 2 : 0);
   constexpr int NCC = NC * (NC + 1) / 2;
   constexpr int HV = 6 + 2 * NC + 2;   // doubles handed over per lane and step: Jq (6) | Jc (2 NC) | r (2)
-  static_assert(HV * 256 <= (int)ZD_DOUBLES, "hand-off buffer must fit the Z matrix");
+  constexpr uint32_t LP = 64u * WR;    // lanes of a pass (= threads per role)
+  constexpr uint32_t NT = 2u * LP;     // threads of the workgroup
+  static_assert(HV * LP <= V2Lds::zd_for(LP), "hand-off buffer must fit the Z matrix");
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const V2Lds lay(d.v2_nfmax, true);
+  const V2Lds lay(d.v2_nfmax, true, LP);
   const uint32_t NFm = lay.nfm, vlen = 6 * NFm + NCMAX + 3;
   double* Spp = sm; double* Scp = sm + lay.off_cp; double* Scc = sm + lay.off_cc;
   double* vgB = sm + lay.off_vec; double* vhd = vgB + vlen; double* vrhs = vhd + vlen;
@@ -35,10 +43,18 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
   double* misc = sm + lay.off_misc;   // [0] cost, [1] bad-U count, [2] max |g_p| (as bits)
   uint32_t* pidl = (uint32_t*)(misc + 8);
   unsigned short* colinfo = (unsigned short*)(misc + 8 + 32);
-  const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
-  const bool role_b = w >= 4;             // accumulator waves
-  const uint32_t wl = w & 3u;             // tile of the pass this wave works on
-  const uint32_t t256 = tid & 255u;       // lane slot of the pass (the same for the evaluator and its accumulator)
+  // WR == 2: the four waves of a workgroup sit on the four SIMDs of the CU, one each, so a workgroup alone would put both evaluator
+  // waves (300 VALU instructions per step) on SIMDs 0-1 and both accumulators (200) on SIMDs 2-3.  The second workgroup of the CU
+  // (its LDS allocation does not start at 0) swaps the roles of its wave pairs, so that every SIMD hosts one evaluator and one
+  // accumulator, as with four waves per role.  (LIFCAL_NO_ROLE_FLIP in the build disables it: A/B measurement.)
+  uint32_t flip = 0;
+#ifndef LIFCAL_NO_ROLE_FLIP
+  if (WR == 2) flip = (__builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)) != 0) ? LP : 0u;   // HW_REG_LDS_ALLOC.LDS_BASE
+#endif
+  const uint32_t tid = threadIdx.x ^ flip, lane = tid & 63u, w = tid >> 6;
+  const bool role_b = w >= (uint32_t)WR;  // accumulator waves
+  const uint32_t wl = w & (uint32_t)(WR - 1);   // tile of the pass this wave works on
+  const uint32_t t256 = tid & (LP - 1u);  // lane slot of the pass (the same for the evaluator and its accumulator)
   const uint32_t b = blockIdx.x;
   const uint32_t flo = d.blk_flo[b], nf = d.blk_nf[b];
   const uint32_t ncol = 6 * nf + NC + 1, ncolp = (ncol + 15u) & ~15u;
@@ -46,8 +62,8 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
   const CamConsts c = *d.camc;
 #ifdef LIFCAL_STAMPS
   unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, st_last = 0;
-  if (tid == 0 || tid == 256) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); }
-#define STAMPB(i) do { if (tid == 256) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[i] += t_ - st_last; st_last = t_; } } while (0)
+  if (tid == 0 || tid == LP) { asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last) :: "memory"); }
+#define STAMPB(i) do { if (tid == LP) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_acc[i] += t_ - st_last; st_last = t_; } } while (0)
 #else
 #define STAMPB(i) do { } while (0)
 #endif
@@ -58,29 +74,29 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
   asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
   auto fetch_pass = [&](uint32_t q) {
     nx_np = d.pass_np[q + vz]; nx_gid0 = d.pass_gid0[q + vz];
-    nx_si = d.v2_slot[(size_t)q * 256 + t256]; nx_pt = d.v2f_pt[(size_t)q * 256 + t256]; nx_gid = d.v2_gidx[(size_t)q * 256 + t256];
-    nx_r[0] = d.v2_tile_row0[q * 4 + wl + vz]; nx_r[1] = d.v2_tile_row0[q * 4 + wl + 1 + vz];   // observation rows of the wave's tile
+    nx_si = d.v2_slot[(size_t)q * LP + t256]; nx_pt = d.v2f_pt[(size_t)q * LP + t256]; nx_gid = d.v2_gidx[(size_t)q * LP + t256];
+    nx_r[0] = d.v2_tile_row0[q * WR + wl + vz]; nx_r[1] = d.v2_tile_row0[q * WR + wl + 1 + vz];   // observation rows of the wave's tile
     nx_fp = d.v2_passpt[(size_t)q * 64 + (tid & 63u)];
   };
   if (ps_begin < ps_end) fetch_pass(ps_begin);
-  { double2* z2 = reinterpret_cast<double2*>(sm); for (uint32_t i = tid; i < lay.off_slab / 2; i += 512) z2[i] = double2{0.0, 0.0}; }
+  { double2* z2 = reinterpret_cast<double2*>(sm); for (uint32_t i = tid; i < lay.off_slab / 2; i += NT) z2[i] = double2{0.0, 0.0}; }
   if (tid == 0 && (lay.off_slab & 1u)) sm[lay.off_slab - 1] = 0.0;
   if (tid < 8) misc[tid] = 0.0;
-  for (uint32_t cI = tid; cI < ncolp; cI += 512)
+  for (uint32_t cI = tid; cI < ncolp; cI += NT)
     colinfo[cI] = (cI < 6 * nf) ? (unsigned short)(((cI / 6) << 8) | (cI % 6)) : (cI < ncol - 1 ? (unsigned short)(0x8000u | (cI - 6 * nf)) : (unsigned short)0xC000u);
 
   // ---- phases both roles run with all 512 threads ----
-  auto zero_slab = [&]() { for (uint32_t i = tid; i < 64 * 12; i += 512) slab[i] = 0.0; };
-  auto zero_zd = [&](uint32_t krows) { double2* z2 = reinterpret_cast<double2*>(Zd); for (uint32_t i = tid; i < (krows * zs) / 2; i += 512) z2[i] = double2{0.0, 0.0}; };
+  auto zero_slab = [&]() { for (uint32_t i = tid; i < lay.np_max * 12; i += NT) slab[i] = 0.0; };
+  auto zero_zd = [&](uint32_t krows) { double2* z2 = reinterpret_cast<double2*>(Zd); for (uint32_t i = tid; i < (krows * zs) / 2; i += NT) z2[i] = double2{0.0, 0.0}; };
   // Z = L^-1 W in place (pose + camera columns), camera part of W to HBM first; thread = (column, point phase)
   auto z_phase = [&](uint32_t np) {
     const uint32_t nwc = ncol - 1;
-    const uint32_t nth = 512 / nwc > 0 ? 512 / nwc : 1;
+    const uint32_t nth = NT / nwc > 0 ? NT / nwc : 1;
     const uint32_t gi = tid / nwc, cidx = tid - gi * nwc;
-    if (gi < nth || nwc > 512) {
-      for (uint32_t cc0 = cidx; cc0 < nwc; cc0 += (nwc > 512 ? 512 : nwc * nth)) {
+    if (gi < nth || nwc > NT) {
+      for (uint32_t cc0 = cidx; cc0 < nwc; cc0 += (nwc > NT ? NT : nwc * nth)) {
 #pragma unroll 4
-        for (uint32_t lp = (nwc > 512 ? 0 : gi); lp < np; lp += (nwc > 512 ? 1 : nth)) {
+        for (uint32_t lp = (nwc > NT ? 0 : gi); lp < np; lp += (nwc > NT ? 1 : nth)) {
           const double* acc = slab + lp * 12;
           double* z = Zd + (size_t)(3 * lp) * zs + cc0;
           const double w0 = z[0], w1 = z[zs], w2 = z[2 * zs];
@@ -221,8 +237,11 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       }
     }
   };
-  const bool keep_tiles = (mode == 0) && ntri <= 256;
+  // WR == 2: 128 threads per role cannot own the ~230 tiles of a 12-frame window one each; all 256 threads share the tiles of
+  // every pass (fresh accumulators per pass, Spp -= tile at its end)
+  const bool keep_tiles = (WR == 4) && (mode == 0) && ntri <= LP;
   const bool ksplit = keep_tiles && lay.has_bt();
+  const bool share_tiles = (WR != 4) && (mode == 0);
   double* bt = sm + lay.off_bt;   // [16][256] partial tiles of the accumulator threads
   if (!role_b) {
     // =====================================================================================================================
@@ -255,16 +274,21 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       STAMP(0);
       const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = (si >> 16) & 0xFFu;
       const uint32_t fr = flo + lf;
-      GroupConsts2 gcn;
+      typename std::conditional<F32, GroupConsts2F, GroupConsts2>::type gcn;
       {
         const double* ft = d.ft + (size_t)fr * FRAME_STRIDE;
         const double* P = d.pts + 3 * (size_t)pt;
         const double P0 = P[0], P1 = P[1], P2 = P[2];
-        group_prepare2<ADJ>(c, ft[0] * P0 + ft[1] * P1 + ft[2] * P2 + ft[9], ft[3] * P0 + ft[4] * P1 + ft[5] * P2 + ft[10],
-                            ft[6] * P0 + ft[7] * P1 + ft[8] * P2 + ft[11], gcn);
+        const double Xc = ft[0] * P0 + ft[1] * P1 + ft[2] * P2 + ft[9], Yc = ft[3] * P0 + ft[4] * P1 + ft[5] * P2 + ft[10], Zc = ft[6] * P0 + ft[7] * P1 + ft[8] * P2 + ft[11];
+        if constexpr (F32) group_prepare2f<ADJ>(c, Xc, Yc, Zc, gcn); else group_prepare2<ADJ>(c, Xc, Yc, Zc, gcn);
       }
       double A[6] = {0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0};
-      double* hand = Zd + t256;
+      ET* hand = reinterpret_cast<ET*>(Zd) + t256;
+      constexpr uint32_t HS = LP;   // stride between the values of the hand-off buffer
+      // observation words of the evaluation type: (u, v) in fp64, (u - mcx, v - mcy) in fp32; lens rows of 16 ET
+      const ET* obs_u = F32 ? reinterpret_cast<const ET*>(d.v2_du) : reinterpret_cast<const ET*>(d.v2_u);
+      const ET* obs_v = F32 ? reinterpret_cast<const ET*>(d.v2_dv) : reinterpret_cast<const ET*>(d.v2_v);
+      const ET* lens_tab = F32 ? reinterpret_cast<const ET*>(d.ltf) : reinterpret_cast<const ET*>(d.lt);
       // two-stage prefetch: observation words (u, v, lens index) two steps ahead, the 128-byte lens row one step ahead; the
       // row's registers are free at the end of a step (the evaluation consumes the row first), so the peak does not grow.
       // All prefetch loads are UNCONDITIONAL (row index clamped; the ELL padding is valid memory): with loads under a lane
@@ -272,59 +296,62 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       // wait for the prefetch it has just issued (HBM latency, every step).
       // The loop is unrolled by two over two sets of observation words (even / odd steps): a rotating set would make the
       // compiler copy freshly loaded registers at the back-edge, i.e. wait for the loads it has just issued.
-      double ua = 0.0, va = 0.0, ub = 0.0, vb = 0.0; uint32_t lb = 0, la = 0;
-      double Ln[LENS_STRIDE];
+      ET ua = 0, va = 0, ub = 0, vb = 0; uint32_t lb = 0, la = 0;
+      ET Ln[LENS_STRIDE];
 #pragma unroll
-      for (int i = 0; i < LENS_STRIDE; ++i) Ln[i] = 0.0;
+      for (int i = 0; i < LENS_STRIDE; ++i) Ln[i] = 0;
       if (kmax > 0) {
         const size_t at = (size_t)row0 * 64 + lane;
-        ua = d.v2_u[at]; va = d.v2_v[at];
-        const double* L = d.lt + (size_t)d.v2_lens[at] * LENS_STRIDE;
+        ua = obs_u[at]; va = obs_v[at];
+        const ET* L = lens_tab + (size_t)d.v2_lens[at] * LENS_STRIDE;
 #pragma unroll
         for (int i = 0; i < LENS_STRIDE; ++i) Ln[i] = L[i];
         const size_t at2 = ((size_t)row0 + (kmax > 1 ? 1u : 0u)) * 64 + lane;
-        ub = d.v2_u[at2]; vb = d.v2_v[at2]; lb = d.v2_lens[at2];
+        ub = obs_u[at2]; vb = obs_v[at2]; lb = d.v2_lens[at2];
       }
+      typename std::conditional<F32, CamF, int>::type cf{};
+      if constexpr (F32) cf = cam_to_float(c);
       // one step: evaluate with (uc, vc, Ln), then fetch the lens row of step k+1 (index ln, arrived a step ago) and the
       // words of step k+2 into the set just consumed
-      auto step = [&](uint32_t k, double& uc, double& vc, uint32_t& lc, const uint32_t ln) {
+      auto step = [&](uint32_t k, ET& uc, ET& vc, uint32_t& lc, const uint32_t ln) {
         // the hand-off buffer is free once the accumulator has taken step k-1 (it did so long ago: checked first, so that
         // the evaluation's results can go to LDS as they are produced instead of staying live)
         wait_for(hw_read, hbase + k);
         if (k < cnt) {
-          const double u = uc, v = vc;
-          double L[LENS_STRIDE];
+          const ET u = uc, v = vc;
+          ET L[LENS_STRIDE];
 #pragma unroll
           for (int i = 0; i < LENS_STRIDE; ++i) L[i] = Ln[i];
-          double r[2], Jq[2][3], Jc[2][NC];
-          double arg;
-          obs_eval2<NR, TAN, ADJ>(c, gcn, L, u, v, d.robust != 0, r, Jq, Jc, arg);
+          ET r[2], Jq[2][3], Jc[2][NC];
+          ET arg;
+          if constexpr (F32) obs_eval2f<NR, TAN, ADJ>(cf, gcn, L, u, v, d.robust != 0, r, Jq, Jc, arg);
+          else obs_eval2<NR, TAN, ADJ>(c, gcn, L, u, v, d.robust != 0, r, Jq, Jc, arg);
           // hand-off to the accumulator wave, [value][lane]
 #pragma unroll
           for (int a = 0; a < 2; ++a) {
 #pragma unroll
-            for (int j = 0; j < NC; ++j) hand[(6 + a * NC + j) * 256] = Jc[a][j];
+            for (int j = 0; j < NC; ++j) hand[(6 + a * NC + j) * HS] = Jc[a][j];
 #pragma unroll
-            for (int i = 0; i < 3; ++i) hand[(a * 3 + i) * 256] = Jq[a][i];
-            hand[(6 + 2 * NC + a) * 256] = r[a];
+            for (int i = 0; i < 3; ++i) hand[(a * 3 + i) * HS] = Jq[a][i];
+            hand[(6 + 2 * NC + a) * HS] = r[a];
           }
-          if (d.robust) { int ex; lmant = frexp(lmant * arg, &ex); lexp += ex; }   // rho = b log(prod (1 + s/b)): one log per lane at the end
-          else cost += 0.5 * arg;
+          if (d.robust) { int ex; lmant = frexp(lmant * (double)arg, &ex); lexp += ex; }   // rho = b log(prod (1 + s/b)): one log per lane at the end
+          else cost += 0.5 * (double)arg;
 #pragma unroll
-          for (int a = 0; a < 2; ++a) {
-            A[0] += Jq[a][0] * Jq[a][0]; A[1] += Jq[a][0] * Jq[a][1]; A[2] += Jq[a][0] * Jq[a][2];
-            A[3] += Jq[a][1] * Jq[a][1]; A[4] += Jq[a][1] * Jq[a][2]; A[5] += Jq[a][2] * Jq[a][2];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) bv[i] += Jq[a][i] * r[a];
+          for (int a = 0; a < 2; ++a) {   // (fp64 accumulation, whatever the evaluation type)
+            const double q0 = Jq[a][0], q1 = Jq[a][1], q2 = Jq[a][2], ra = r[a];
+            A[0] += q0 * q0; A[1] += q0 * q1; A[2] += q0 * q2;
+            A[3] += q1 * q1; A[4] += q1 * q2; A[5] += q2 * q2;
+            bv[0] += q0 * ra; bv[1] += q1 * ra; bv[2] += q2 * ra;
           }
         }
         {
-          const double* Lp = d.lt + (size_t)ln * LENS_STRIDE;
+          const ET* Lp = lens_tab + (size_t)ln * LENS_STRIDE;
 #pragma unroll
           for (int i = 0; i < LENS_STRIDE; ++i) Ln[i] = Lp[i];
           const uint32_t kk = (k + 2 < kmax) ? k + 2 : kmax - 1;
           const size_t at = ((size_t)row0 + kk) * 64 + lane;
-          uc = d.v2_u[at]; vc = d.v2_v[at]; lc = d.v2_lens[at];
+          uc = obs_u[at]; vc = obs_v[at]; lc = d.v2_lens[at];
         }
         publish(hw_written, hbase + k + 1);
       };
@@ -410,7 +437,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_fetch_add(eval_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       ++passes_done;
-      if (w == 0) wait_for(eval_done, 4u * passes_done);
+      if (w == 0) wait_for(eval_done, (uint32_t)WR * passes_done);
       STAMP(1);
       // ---- one thread per point: damp, factor U = L L^T (k_sweep2 phase 2) ----
       if (tid < np) {
@@ -463,7 +490,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
         if (keep_tiles) {
           if (tid < ntri) gemm_tile(mi0, mj0, 0, ksplit ? 8u : 4u, krows, tacc);
         } else {
-          for (uint32_t t = tid; t < ntri; t += 256) {
+          for (uint32_t t = tid; t < ntri; t += (share_tiles ? NT : LP)) {
             uint32_t mi, mj; tri_decode(t, mi, mj);
             double acc16[4][4];
 #pragma unroll
@@ -484,7 +511,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) tacc[i][j] += bt[(i * 4 + j) * 256 + tid];
+          for (int j = 0; j < 4; ++j) tacc[i][j] += bt[(i * 4 + j) * LP + tid];
       }
       emit_tile(mi0, mj0, tacc);
     }
@@ -521,7 +548,8 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < NC; ++j) C[i][j] = 0.0;
-      const double* hand = Zd + t256;
+      const ET* hand = reinterpret_cast<const ET*>(Zd) + t256;
+      constexpr uint32_t HS = LP;
       for (uint32_t k = 0; k < kmax; ++k) {
         wait_for(hw_written, hbase + k + 1);
         const bool live = k < cnt;
@@ -533,10 +561,10 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
           for (int j = 0; j < NC; ++j) Jc[j] = 0.0;
           if (live) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) Jq[i] = hand[(a * 3 + i) * 256];
+            for (int i = 0; i < 3; ++i) Jq[i] = hand[(a * 3 + i) * HS];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) Jc[j] = hand[(6 + a * NC + j) * 256];
-            r = hand[(6 + 2 * NC + a) * 256];
+            for (int j = 0; j < NC; ++j) Jc[j] = hand[(6 + a * NC + j) * HS];
+            r = hand[(6 + 2 * NC + a) * HS];
           }
           if (a == 1) publish(hw_read, hbase + k + 1);
           if (live) {
@@ -599,12 +627,24 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) acc16[i][j] = bt[(i * 4 + j) * 256 + t256];
+          for (int j = 0; j < 4; ++j) acc16[i][j] = bt[(i * 4 + j) * LP + t256];
         gemm_tile(mi, mj, 4, 8, krows, acc16);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bt[(i * 4 + j) * 256 + t256] = acc16[i][j];
+          for (int j = 0; j < 4; ++j) bt[(i * 4 + j) * LP + t256] = acc16[i][j];
+      }
+      if (share_tiles) {   // the accumulator threads' share of the pass's tiles (see the evaluator branch)
+        for (uint32_t t = tid; t < ntri; t += NT) {
+          uint32_t mi, mj; tri_decode(t, mi, mj);
+          double acc16[4][4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc16[i][j] = 0.0;
+          gemm_tile(mi, mj, 0, 4, krows, acc16);
+          emit_tile(mi, mj, acc16);
+        }
       }
       lds_barrier();                                                                                    // ---- barrier P6
       STAMPB(5);
@@ -625,15 +665,16 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
 #pragma unroll
       for (int v = 0; v < RVB; ++v) {
         const int idx = round * RVB + v;
-        if (idx < NVB) Zd[v * 264 + t256] = (idx < NCC) ? cc[idx < NCC ? idx : 0] : gc[(idx - NCC) >= 0 && (idx - NCC) < NC ? idx - NCC : 0];
+        if (idx < NVB) Zd[v * (LP + 8) + t256] = (idx < NCC) ? cc[idx < NCC ? idx : 0] : gc[(idx - NCC) >= 0 && (idx - NCC) < NC ? idx - NCC : 0];
       }
       lds_barrier();                                                                                    // ---- barrier T1
-      if (t256 < RVB * 8) {
-        const int v = t256 >> 3, part = t256 & 7, idx = round * RVB + v;
+      constexpr int NPART = (int)LP / 32;   // partial sums per value: 32 entries each
+      if (t256 < RVB * NPART) {
+        const int v = t256 / NPART, part = t256 % NPART, idx = round * RVB + v;
         if (idx < NVB) {
           double sacc = 0.0;
 #pragma unroll 8
-          for (int k = 0; k < 32; ++k) sacc += Zd[v * 264 + part + 8 * k];
+          for (int k = 0; k < 32; ++k) sacc += Zd[v * (LP + 8) + part + NPART * k];
           if (idx < NCC) {
             int i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i;
             if (mode == 0) atomicAdd(Scc + idx, sacc);
@@ -651,7 +692,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
   // =======================================================================================================================
   lds_barrier();
   STAMP(10);
-  for (uint32_t i = tid; i < FRV * nf; i += 512) {
+  for (uint32_t i = tid; i < FRV * nf; i += NT) {
     const uint32_t v = i / nf, lf = i % nf;
     double sacc = 0.0;
     for (uint32_t r = 0; r < lay.nrep; ++r) sacc += Fr[(size_t)v * NFm * lay.nrep + r * NFm + lf];
@@ -670,11 +711,11 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
   lds_barrier();
   STAMP(11);
   const uint32_t F6 = 6 * d.F, camrow = 3 * d.Q, camcol = F6 + 3 * d.Q;
-  for (uint32_t i = tid; i < 6 * nf; i += 512) atomicAdd(d.hdiag + 6 * flo + i, vhd[i]);
+  for (uint32_t i = tid; i < 6 * nf; i += NT) atomicAdd(d.hdiag + 6 * flo + i, vhd[i]);
   if (tid < (uint32_t)NC) atomicAdd(d.hdiag + camcol + tid, vhd[6 * NFm + tid]);
   if (mode == 0) {
     const uint32_t npp = nf * (nf + 1) / 2;
-    for (uint32_t i = tid; i < npp * 36; i += 512) {
+    for (uint32_t i = tid; i < npp * 36; i += NT) {
       const uint32_t blk = i / 36, e = i % 36;
       uint32_t a = (uint32_t)((sqrtf(8.0f * (float)blk + 1.0f) - 1.0f) * 0.5f);
       while (a * (a + 1) / 2 > blk) --a;
@@ -683,7 +724,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       const double v = Spp[i];
       if (dd <= d.bw && v != 0.0 && !(dd == 0 && (e % 6) > (e / 6))) atomicAdd(d.Sband + ((size_t)(flo + a) * (d.bw + 1) + dd) * 36 + e, v);
     }
-    for (uint32_t i = tid; i < (uint32_t)NC * 6 * nf; i += 512) {
+    for (uint32_t i = tid; i < (uint32_t)NC * 6 * nf; i += NT) {
       const uint32_t j = i / (6 * nf), cidx = i % (6 * nf);
       atomicAdd(d.Sarrow + (size_t)(camrow + j) * d.ld + 6 * flo + cidx, Scp[(size_t)j * 6 * NFm + cidx]);
     }
@@ -692,7 +733,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
       const uint32_t j = tid - i * (i + 1) / 2;
       atomicAdd(d.Sarrow + (size_t)(camrow + i) * d.ld + camcol + j, Scc[tid]);
     }
-    for (uint32_t i = tid; i < 6 * nf; i += 512) { atomicAdd(d.gB + 6 * flo + i, vgB[i]); atomicAdd(d.rhsacc + 6 * flo + i, vrhs[i]); }
+    for (uint32_t i = tid; i < 6 * nf; i += NT) { atomicAdd(d.gB + 6 * flo + i, vgB[i]); atomicAdd(d.rhsacc + 6 * flo + i, vrhs[i]); }
     if (tid < (uint32_t)NC) { atomicAdd(d.gB + camcol + tid, vgB[6 * NFm + tid]); atomicAdd(d.rhsacc + camcol + tid, vrhs[6 * NFm + tid]); }
     if (tid == 0) {
       atomicAdd(d.scal + SCAL_COST, misc[0]);
@@ -703,7 +744,7 @@ __global__ __launch_bounds__(512) void k_sweep3(Dev d, double radius, int mode) 
 #ifdef LIFCAL_STAMPS
   lds_barrier();
   STAMP(5);
-  if ((tid == 0 || tid == 256) && d.dbg) for (int i = 0; i < 16; ++i) d.dbg[(size_t)b * 32 + (tid >> 8) * 16 + i] = st_acc[i];
+  if ((tid == 0 || tid == LP) && d.dbg) for (int i = 0; i < 16; ++i) d.dbg[(size_t)b * 32 + (tid == 0 ? 0 : 16) + i] = st_acc[i];
 #endif
 }
 

@@ -125,6 +125,8 @@ def baseline_spec(name: str) -> SceneSpec:
         return SceneSpec(2000, 100000, 10, 0xF06, s + 5, outlier_fraction=0.02, recalib=True)
     if name == "metric":  # 1.0 M observations (48.3 micro-image observations per point with this MLA)
         return SceneSpec(334, 20700, 10, 0xF06, s + 6, outlier_fraction=0.02)
+    if name == "metric_web":  # 1.0 M observations when the lenses are chosen by the reference's own generator (make_scene(lens_selector=...):
+        return SceneSpec(334, 24720, 10, 0xF06, s + 6, outlier_fraction=0.02)   # 4.05 micro images per (point, frame) instead of 4.85)
     if name == "tiny":   # smoke / unit tests
         return SceneSpec(6, 40, None, 0x506, s + 7)
     raise KeyError(name)
@@ -276,7 +278,13 @@ class Scene:
         return int(self.u.shape[0])
 
 
-def make_scene(spec: SceneSpec) -> Scene:
+def make_scene(spec: SceneSpec, lens_selector=None) -> Scene:
+    """lens_selector: None = the K nearest lens centres filtered by the search radius of reference :692 (a numpy stand-in for the
+    reference's walk along the epipolar web, which finds ~4 % more lenses than the web does); or a callable
+    (img_x, img_y, img_vd, img_fr, img_pt, scale) -> (src, mcx, mcy) that returns, for the frame-major virtual-image points, the lenses
+    the reference's own generator visits (CameraCalibration::projectPointsToRawImage, src/CameraCalibration.cpp:637-769) — bench.py
+    passes the GPU port of it (lifcal_mla_project), tests pass the oracle's.  Either way the observation VALUES are the forward model
+    at ground truth + noise, and an observation is kept if it lies inside its micro image and inside the sensor (:754-759)."""
     F, P = spec.n_frames, spec.n_points
     n_rad = spec.config & 3
     tan = bool(spec.config & CFG_TANGENTIAL)
@@ -341,25 +349,33 @@ def make_scene(spec: SceneSpec) -> Scene:
     ok &= (x_ups >= 0) & (x_ups <= spec.raw_width - 1) & (y_ups >= 0) & (y_ups <= spec.raw_height - 1)
     pf_p, pf_f, pc, x_ups, y_ups, vdn = pf_p[ok], pf_f[ok], pc[ok], x_ups[ok], y_ups[ok], vdn[ok]
 
-    # lenses that can image the point: K nearest centres, then the exact model + validity radius
+    # lenses that can image the point, then the exact model + validity radius
     lenses = make_lens_grid(spec).astype(np.float64)
-    from scipy.spatial import cKDTree
-
-    K = 24
-    tree = cKDTree(lenses)
-    _, nn = tree.query(np.stack([x_ups, y_ups], -1), k=K)
     n_pf = pf_p.shape[0]
-    cand_pf = np.repeat(np.arange(n_pf), K)
-    cand_l = nn.reshape(-1)
-    ml = lenses[cand_l]
+    img = _image_points(pf_p, pf_f, x_ups, y_ups, vdn, spec.scale)
+    if lens_selector is None:
+        from scipy.spatial import cKDTree
+
+        K = 24
+        tree = cKDTree(lenses)
+        _, nn = tree.query(np.stack([x_ups, y_ups], -1), k=K)
+        cand_pf = np.repeat(np.arange(n_pf), K)
+        cand_l = nn.reshape(-1)
+        ml = lenses[cand_l]
+    else:
+        img_order = np.lexsort((pf_p, pf_f))   # frame-major position -> candidate pair (the order of _image_points)
+        src, smx, smy = lens_selector(img["img_x"], img["img_y"], img["img_vd"], img["img_fr"], img["img_pt"], spec.scale)
+        cand_pf = img_order[np.asarray(src, np.int64)]
+        ml = np.stack([np.asarray(smx, np.float64), np.asarray(smy, np.float64)], -1)
     proj = project(pc[cand_pf], ml, cam_gt, spec.config, spx_tot, float(spec.scale))
     d2 = np.sum((proj - ml) ** 2, -1)
     rad_valid = spec.lens_diameter * 0.5 - 1.0
     keep = d2 < rad_valid * rad_valid
     keep &= (proj[:, 0] >= 0) & (proj[:, 0] <= spec.raw_width - 1) & (proj[:, 1] >= 0) & (proj[:, 1] <= spec.raw_height - 1)
-    # reference :692: the lens must lie within lensDiameter/2 * v + 2 px of the up-sampled point
-    search_r = spec.lens_diameter * 0.5 * vdn[cand_pf] + 2.0
-    keep &= ((ml[:, 0] - x_ups[cand_pf]) ** 2 + (ml[:, 1] - y_ups[cand_pf]) ** 2) <= search_r * search_r
+    if lens_selector is None:
+        # reference :692: the lens must lie within lensDiameter/2 * v + 2 px of the up-sampled point
+        search_r = spec.lens_diameter * 0.5 * vdn[cand_pf] + 2.0
+        keep &= ((ml[:, 0] - x_ups[cand_pf]) ** 2 + (ml[:, 1] - y_ups[cand_pf]) ** 2) <= search_r * search_r
     cand_pf, ml, proj = cand_pf[keep], ml[keep], proj[keep]
     obs_pt = pf_p[cand_pf]
     obs_fr = pf_f[cand_pf]
@@ -423,7 +439,7 @@ def make_scene(spec: SceneSpec) -> Scene:
         c_i=c_i, c_j=c_j, c_dist=c_dist, c_sigma=c_sigma,
         use_constraints=0 if spec.recalib else 1,
         n_lenses=int(lenses.shape[0]),
-        **_image_points(pf_p, pf_f, x_ups, y_ups, vdn, spec.scale),
+        **img,
     )
 
 

@@ -45,6 +45,28 @@ def bounded_problem(sc):
                               fixed_mask=0b101, lower=lower, upper=upper)
 
 
+def oracle_lens_selector(spec):
+    """lens_selector for scene.make_scene built on the oracle's restatement of the reference's observation generator
+    (oracle/lifcal_mla.cpp: projectPointsToRawImage with the lens maps and the epipolar web, reference src/CameraCalibration.cpp:637-769)"""
+    from oracle import mla as omla
+    grid = omla.MicroLensGrid(spec.raw_width, spec.raw_height, spec.lens_diameter, spec.lens_base_y, spec.grid_rotation, spec.grid_offset, True)
+
+    def select(img_x, img_y, img_vd, img_fr, img_pt, scale):
+        src, mx, my = [], [], []
+        fr = np.asarray(img_fr)
+        bounds = np.flatnonzero(np.diff(fr)) + 1
+        starts = np.concatenate([[0], bounds]); ends = np.concatenate([bounds, [len(fr)]])
+        for a, b in zip(starts, ends):
+            if b <= a:
+                continue
+            o = grid.project_frame(img_x[a:b], img_y[a:b], img_vd[a:b], int(scale))
+            src.append(o.point + a); mx.append(o.cX); my.append(o.cY)
+        if not src:
+            return np.zeros(0, np.int64), np.zeros(0), np.zeros(0)
+        return np.concatenate(src), np.concatenate(mx), np.concatenate(my)
+    return select
+
+
 def free_port():
     """a TCP port the kernel just handed out (rendezvous of the multi-process tests)"""
     import socket

@@ -152,7 +152,7 @@ def test_empty_and_degenerate_problems(built):
     assert info.n_groups == 0 and info.n_tiles == 0 and info.n_chunks == 0 and len(order) == 0
     one = capi.ProblemArrays(sc.u[:1], sc.v[:1], sc.mcx[:1], sc.mcy[:1], sc.pt[:1], sc.fr[:1], sc.cam0, sc.views0, sc.pts0, sc.spx, sc.scale, sc.config)
     info, order, owner = plan(one)
-    assert info.n_groups == 1 and info.n_tiles in (1, 4) and info.max_group_obs == 1
+    assert info.n_groups == 1 and info.n_tiles in (1, 2, 4) and info.max_group_obs == 1   # one v1 tile, or the two / four tiles of one LDS-window pass
 
 
 def test_planner_threads_do_not_change_the_layout(built, capfd, monkeypatch):

@@ -39,3 +39,21 @@ def test_lens_grid_is_hexagonal():
     d, _ = cKDTree(g).query(g, k=7)
     inner = (g[:, 0] > 200) & (g[:, 0] < 1800) & (g[:, 1] > 200) & (g[:, 1] < 1800)
     assert np.allclose(d[inner, 1:], 23.2, atol=0.02)              # six neighbours at one lens pitch
+
+
+def test_scene_with_the_reference_generators_lens_selection():
+    """make_scene(lens_selector=...): the lenses that see a point come from the reference's own walk (nearest lens + epipolar web,
+    src/CameraCalibration.cpp:661-752, here the oracle's restatement) instead of the K-nearest stand-in; observation values stay the
+    forward model at ground truth + noise.  The web finds a subset of what the stand-in accepts (~4 % fewer)."""
+    from tests.helpers import S, oracle_lens_selector
+    spec = S(6, 60, None, 0xF06, 4711)
+    a = scene.make_scene(spec)
+    b = scene.make_scene(spec, lens_selector=oracle_lens_selector(spec))
+    assert 0.85 * a.n_obs < b.n_obs <= 1.02 * a.n_obs
+    key = lambda sc: set(zip(sc.pt.tolist(), sc.fr.tolist(), np.round(sc.mcx, 3).tolist(), np.round(sc.mcy, 3).tolist()))
+    ka, kb = key(a), key(b)
+    assert len(kb - ka) <= 0.03 * len(kb)          # (doubled web lines of a rotated grid list a few lenses twice; the set view drops them)
+    assert np.array_equal(a.cam0, b.cam0) and np.array_equal(a.pts_gt, b.pts_gt) and np.array_equal(a.img_x, b.img_x)
+    # every observation lies inside its micro image and is the model's projection up to the noise
+    d = np.hypot(b.u - b.mcx, b.v - b.mcy)
+    assert d.max() < spec.lens_diameter / 2 - 1.0 + 5 * spec.noise_px + 1e-9
