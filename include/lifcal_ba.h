@@ -211,6 +211,27 @@ int lifcal_ba_reproj_stats(lifcal_ba_handle* h, double inlier_threshold, lifcal_
  * With world_size > 1 a rank fills the observations of the points it owns and leaves NaN elsewhere. */
 int lifcal_ba_project_observations(lifcal_ba_handle* h, double* x_proj, double* y_proj);
 
+/* Poses held constant: fixed[f] != 0 keeps views[6f..6f+5] at their stored values in every following sweep / solve (ceres
+ * SetParameterBlockConstant on that pose block: the frame's observations still constrain camera and points, its six columns
+ * leave the reduced system).  fixed == NULL frees all poses again.  No reference counterpart; it is what the frame-windowed
+ * driver below needs to carry finished frames into the next window (BASELINE configs[4] "streaming"). */
+int lifcal_ba_set_fixed_frames(lifcal_ba_handle* h, const uint8_t* fixed /* [n_frames] or NULL */);
+
+/* Frame-windowed ("streaming") bundle adjustment for long sequences (BASELINE configs[4]: recalib, 2000 frames): the frame axis is
+ * cut into windows of `window_frames` frames that advance by window_frames - overlap_frames; each window is ONE ordinary problem
+ * (its frames, the points they observe, the camera block with the caller's fixed_mask / bounds) created, solved and destroyed
+ * in turn, so only one window is resident on the device.  From the second window on, the first overlap_frames poses — already
+ * refined by the previous window — are held constant, and points whose observations all lie in earlier windows keep their
+ * values.  Parameters are updated in place like lifcal_ba_solve; `per_window`, if not NULL, receives one summary per window
+ * (capacity *n_windows on entry, count on return).  With world_size > 1 every window is sharded by 3D point as usual; the
+ * collective hooks / communicator of `comm_template` (a handle created on the SAME options, may be NULL at world_size 1) are reused. */
+typedef struct lifcal_ba_window_report {
+  uint32_t first_frame, n_frames, n_fixed_frames, n_points, n_obs;
+  lifcal_ba_summary summary;
+} lifcal_ba_window_report;
+int lifcal_ba_solve_windowed(const lifcal_ba_problem* p, const lifcal_ba_options* o, uint32_t window_frames, uint32_t overlap_frames,
+                             lifcal_ba_handle* comm_template, lifcal_ba_window_report* per_window, uint32_t* n_windows);
+
 /* re-upload cam/views/pts from the caller's arrays (e.g. to re-run from a new initial point) */
 int lifcal_ba_upload_parameters(lifcal_ba_handle* h);
 /* copy the device-resident cam/views/pts back into the caller's arrays */

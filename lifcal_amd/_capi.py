@@ -73,6 +73,11 @@ class Profile(C.Structure):
                 ("ms_schur", C.c_double), ("ms_total", C.c_double)]
 
 
+class WindowReport(C.Structure):   # lifcal_ba_window_report
+    _fields_ = [("first_frame", C.c_uint32), ("n_frames", C.c_uint32), ("n_fixed_frames", C.c_uint32), ("n_points", C.c_uint32), ("n_obs", C.c_uint32),
+                ("summary", Summary)]
+
+
 class PlanInfo(C.Structure):
     _fields_ = [("n_groups", C.c_uint32), ("n_tiles", C.c_uint32), ("n_lenses", C.c_uint32), ("n_promoted", C.c_uint32),
                 ("n_reduced", C.c_uint32), ("max_group_obs", C.c_uint32), ("n_chunks", C.c_uint32),
@@ -186,6 +191,8 @@ PROTOTYPES = {
     "lifcal_ba_profile_end": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "lifcal_ba_reproj_stats": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(Stats)]),
     "lifcal_ba_project_observations": (C.c_int, [C.c_void_p, dptr, dptr]),
+    "lifcal_ba_set_fixed_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint8)]),
+    "lifcal_ba_solve_windowed": (C.c_int, [C.POINTER(Problem), C.POINTER(Options), C.c_uint32, C.c_uint32, C.c_void_p, C.POINTER(WindowReport), C.POINTER(C.c_uint32)]),
     "lifcal_ba_upload_parameters": (C.c_int, [C.c_void_p]),
     "lifcal_ba_download_parameters": (C.c_int, [C.c_void_p]),
     "lifcal_ba_set_allreduce": (C.c_int, [C.c_void_p, ALLREDUCE_FN, C.c_void_p]),

@@ -95,6 +95,15 @@ class BundleAdjustment:
         _check(self.lib, self.lib.lifcal_ba_project_observations(self._h, capi.as_dptr(x), capi.as_dptr(y)), "lifcal_ba_project_observations")
         return x, y
 
+    def set_fixed_frames(self, fixed=None):
+        """hold the poses of the frames with fixed[f] != 0 constant in the following sweeps / solves (None frees all)"""
+        if fixed is None:
+            _check(self.lib, self.lib.lifcal_ba_set_fixed_frames(self._h, None), "lifcal_ba_set_fixed_frames")
+        else:
+            m = np.ascontiguousarray(fixed, np.uint8)
+            assert len(m) == self.problem.struct.n_frames
+            _check(self.lib, self.lib.lifcal_ba_set_fixed_frames(self._h, m.ctypes.data_as(C.POINTER(C.c_uint8))), "lifcal_ba_set_fixed_frames")
+
     # -- the benchmarked unit ------------------------------------------------------------------
     def sweep(self, radius: float = 1e4, want_matrices: bool = False):
         """One Jacobian+Schur sweep; returns a namespace with cost, gradient_max_norm, seconds and,
@@ -167,6 +176,22 @@ class BundleAdjustment:
     def comm_init_rccl(self, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, 128)
         _check(self.lib, self.lib.lifcal_ba_comm_init_rccl(self._h, buf), "lifcal_ba_comm_init_rccl")
+
+
+def performBundleAdjustmentWindowed(problem: capi.ProblemArrays, window_frames: int, overlap_frames: int, options: Optional[capi.Options] = None,
+                                    comm_template: Optional[BundleAdjustment] = None):
+    """Frame-windowed ("streaming") solve of a long sequence (lifcal_ba_solve_windowed): parameters of `problem` are updated in
+    place, one window resident on the device at a time.  Returns the list of per-window reports."""
+    lib = capi.load_library()
+    if options is None:
+        options = capi.Options(); lib.lifcal_ba_default_options(C.byref(options))
+    step = window_frames - overlap_frames
+    cap = max(1, (problem.struct.n_frames + step - 1) // max(step, 1) + 1)
+    reps = (capi.WindowReport * cap)()
+    n = C.c_uint32(cap)
+    _check(lib, lib.lifcal_ba_solve_windowed(C.byref(problem.struct), C.byref(options), int(window_frames), int(overlap_frames),
+                                             comm_template._h if comm_template is not None else None, reps, C.byref(n)), "lifcal_ba_solve_windowed")
+    return [reps[i] for i in range(n.value)]
 
 
 def comm_unique_id() -> bytes:

@@ -340,8 +340,12 @@ LIFCAL_DEV void obs_eval2(const CamConsts& c, const GroupConsts2& g, const doubl
 //   * the observation is stored relative to its micro-lens centre m (du = u - m.x, dv = v - m.y: a few pixels),
 //   * the lens table carries, per unique lens and computed in fp64, w = (a) c_u [mm] and the small pixel offset
 //     Lm = w / sp + c_raw - m (mlCenterAdj; 0 otherwise: c_d / sp + c_raw - m vanishes identically),
-//   so r = pMl / sp + Lm + Delta / sp - du is a sum of SMALL terms; the one cancellation left is inside pMl = gamma q - beta w
-//   (point direction against lens direction, ~40 : 1), i.e. ~1e-4 px of rounding on a 0.1 px noise floor.
+//   so r = pMl / sp + Lm + Delta / sp - du is a sum of SMALL terms;
+//   * the one cancellation left, inside pMl = gamma q - beta w (point direction against lens direction, ~40 : 1, which costs
+//     ~1e-4 px in plain fp32), is taken in fp64: pMl = -gamma hZ (w - w0) with hZ = (Z - fL) / ((Z + zC0) fL) and w0 = (X, Y) fL / (Z - fL)
+//     the lens position that images the point onto the lens centre, both per group in fp64; per observation ONE fp64 subtraction
+//     per axis (w comes from a small fp64 side table), the difference (a fraction of a millimetre) continues in fp32.
+//   Measured on BASELINE configs[1]: converged intrinsics within 2e-5 of the fp64 arm without, a few 1e-7 with this step.
 // Group constants are computed in fp64 (group_prepare2) and rounded once.
 struct CamF { float a, e, gamma, beta, isp0, isp1, sp0, sp1, k0, k1, p0, p1, loss_c; };
 LIFCAL_DEV CamF cam_to_float(const CamConsts& c) {
@@ -351,11 +355,14 @@ LIFCAL_DEV CamF cam_to_float(const CamConsts& c) {
   f.k0 = (float)c.k[0]; f.k1 = (float)c.k[1]; f.p0 = (float)c.p[0]; f.p1 = (float)c.p[1]; f.loss_c = (float)c.loss_c;
   return f;
 }
-struct GroupConsts2F { float X, Y, iZq, gz, kq[3], kc[3], gl; };
+struct GroupConsts2F { float X, Y, iZq, gz, kq[3], kc[3], gl, mgx, mgy; double w0x, w0y; };   // mg = -gamma hZ / sp
 template <bool ADJ>
 LIFCAL_DEV void group_prepare2f(const CamConsts& c, double X, double Y, double Z, GroupConsts2F& g) {
   GroupConsts2 d; group_prepare2<ADJ>(c, X, Y, Z, d);
   g.X = (float)d.X; g.Y = (float)d.Y; g.iZq = (float)d.iZq; g.gz = (float)d.gz; g.gl = (float)d.gl;
+  const double izf = 1.0 / (Z - c.fL), hZ = (Z - c.fL) * d.iZq * c.ifL;
+  g.w0x = X * c.fL * izf; g.w0y = Y * c.fL * izf;
+  g.mgx = (float)(-c.gamma * hZ * c.isp[0]); g.mgy = (float)(-c.gamma * hZ * c.isp[1]);
 #pragma unroll
   for (int i = 0; i < 3; ++i) { g.kq[i] = (float)d.kq[i]; g.kc[i] = (float)(ADJ ? d.kc[i] / c.a : d.kc[i]); }   // multiplies w = a c_u instead of c_u
 }
@@ -389,7 +396,7 @@ struct DistortionF {
 // fp32 lens-table row (16 floats): [0,1] w = (a) c_u [mm], [2,3] Lm [px], [4+2l, 5+2l] d c_u / d lens-parameter l (as the fp64 row)
 // r, Jq, Jc come back multiplied by sqrt(rho') when robust; arg = 1 + s/b (robust) or s (not robust), as obs_eval2
 template <int NR, bool TAN, bool ADJ>
-LIFCAL_DEV void obs_eval2f(const CamF& c, const GroupConsts2F& g, const float* __restrict__ L, float du, float dv, bool robust,
+LIFCAL_DEV void obs_eval2f(const CamF& c, const GroupConsts2F& g, const float* __restrict__ L, double w64x, double w64y, float du, float dv, bool robust,
                            float r[2], float Jq[2][3], float Jc[2][5 + NR + (TAN ? 2 : 0)], float& arg) {
   constexpr int NA = 2 + NR + (TAN ? 2 : 0);
   constexpr int NC = 3 + NA;
@@ -403,7 +410,8 @@ LIFCAL_DEV void obs_eval2f(const CamF& c, const GroupConsts2F& g, const float* _
   for (int a = 0; a < NA; ++a) { dx[3 + a] = g.gl * L[4 + 2 * a]; dy[3 + a] = g.gl * L[5 + 2 * a]; }
   const float qxZ = -g.gz * qx, qyZ = -g.gz * qy;
   float j00, j01, j02, j10, j11, j12;
-  float r0 = mlx * c.isp0 - du, r1 = mly * c.isp1 - dv;
+  // residual: pMl / sp from the fp64 difference (see above); mlx / mly (plain fp32) only feed the distortion argument
+  float r0 = g.mgx * (float)(w64x - g.w0x) - du, r1 = g.mgy * (float)(w64y - g.w0y) - dv;
   if (ADJ) {
     r0 += L[2]; r1 += L[3];
     if (NR > 0 || TAN) {
@@ -443,10 +451,11 @@ LIFCAL_DEV void obs_eval2f(const CamF& c, const GroupConsts2F& g, const float* _
   for (int j = 0; j < NC; ++j) { Jc[0][j] = dx[j] * s0; Jc[1][j] = dy[j] * s1; }
 }
 
-// the fp32 lens-table row from the fp64 one (k_tables)
+// the fp32 lens-table row from the fp64 one (k_tables), and w in fp64 for the side table
 template <bool ADJ>
-LIFCAL_DEV void lens_row_to_float(const CamConsts& c, const double* row, float* out) {
+LIFCAL_DEV void lens_row_to_float(const CamConsts& c, const double* row, float* out, double* w64) {
   const double wx = ADJ ? row[2] * c.a : row[2], wy = ADJ ? row[3] * c.a : row[3];
+  w64[0] = wx; w64[1] = wy;
   out[0] = (float)wx; out[1] = (float)wy;
   out[2] = ADJ ? (float)(wx * c.isp[0] + c.craw[0] - row[0]) : 0.f;
   out[3] = ADJ ? (float)(wy * c.isp[1] + c.craw[1] - row[1]) : 0.f;

@@ -69,6 +69,7 @@ struct Dev {
   const double *v2_u, *v2_v;
   const float *v2_du, *v2_dv;    // options.precision = 1: observation relative to its micro-lens centre (u - mcx, v - mcy), fp32
   float* ltf;                    // options.precision = 1: fp32 lens table of the CURRENT point (see lens_row_to_float)
+  double* ltw;                   // ... and w = (a) c_u of every lens in fp64 (2 per lens): the one fp64 operand of the fp32 evaluation
   const uint32_t* special_owned;
   // constraints
   const uint32_t *c_i, *c_j, *my_cons, *pt_cons0, *pt_cons_list; const double *c_dist, *c_sigma;
@@ -148,10 +149,11 @@ __global__ __launch_bounds__(256) void k_tables(Dev d, const double* cam, const 
 #pragma unroll
     for (int k = 0; k < LENS_STRIDE; ++k) lt[(size_t)t * LENS_STRIDE + k] = o[k];
     if (ltf) {
-      float of[LENS_STRIDE];
-      if (d.adj) lens_row_to_float<true>(c, o, of); else lens_row_to_float<false>(c, o, of);
+      float of[LENS_STRIDE]; double w64[2];
+      if (d.adj) lens_row_to_float<true>(c, o, of, w64); else lens_row_to_float<false>(c, o, of, w64);
 #pragma unroll
       for (int k = 0; k < LENS_STRIDE; ++k) ltf[(size_t)t * LENS_STRIDE + k] = of[k];
+      d.ltw[2 * (size_t)t] = w64[0]; d.ltw[2 * (size_t)t + 1] = w64[1];
     }
   }
   if (t < d.F) {
@@ -271,22 +273,27 @@ __global__ __launch_bounds__(256) void k_sweep(Dev d) {
       for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) GAG[i][j] = Gr[0][i] * AG[0][j] + Gr[1][i] * AG[1][j] + Gr[2][i] * AG[2][j];
-      // pose-pose block (lower), pose gradient, pose diagonal
+      // pose-pose block (lower), pose gradient, pose diagonal.  A frame whose pose is held constant (lifcal_ba_set_fixed_frames: its
+      // observations still constrain the points, the pose columns do not exist) contributes zeros: the mask is a FACTOR, not a
+      // branch — this kernel keeps its 54 camera accumulators in AGPRs and updates them under the lane masks of the observation
+      // loop; a further divergent region around the scatter is what once made those accumulators lose contributions
       const uint32_t pr = 6 * fr;
       double* Sd = d.Sband + (size_t)fr * (d.bw + 1) * 36;
+      const double fm = d.frame_live[fr] != 0 ? 1.0 : 0.0;
 #pragma unroll
       for (int a = 0; a < 6; ++a)
 #pragma unroll
         for (int bb = 0; bb <= a; ++bb) {
           double v;
           if (a < 3) v = GAG[a][bb]; else if (bb < 3) v = AG[a - 3][bb]; else v = Am[a - 3][bb - 3];
+          v *= fm;
           atomicAdd(Sd + a * 6 + bb, v);
           if (a == bb) atomicAdd(d.hdiag + pr + a, v);
         }
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
-        atomicAdd(d.gB + pr + a, Gr[0][a] * b[0] + Gr[1][a] * b[1] + Gr[2][a] * b[2]);
-        atomicAdd(d.gB + pr + 3 + a, b[a]);
+        atomicAdd(d.gB + pr + a, fm * (Gr[0][a] * b[0] + Gr[1][a] * b[1] + Gr[2][a] * b[2]));
+        atomicAdd(d.gB + pr + 3 + a, fm * b[a]);
       }
       // camera x pose block: cp[j][c] = C^T [Gr | I]
       const uint32_t camrow = 3 * d.Q;
@@ -294,9 +301,9 @@ __global__ __launch_bounds__(256) void k_sweep(Dev d) {
       for (int j = 0; j < NC; ++j) {
         double* row = d.Sarrow + (size_t)(camrow + j) * d.ld + pr;
 #pragma unroll
-        for (int cidx = 0; cidx < 3; ++cidx) atomicAdd(row + cidx, C[0][j] * Gr[0][cidx] + C[1][j] * Gr[1][cidx] + C[2][j] * Gr[2][cidx]);
+        for (int cidx = 0; cidx < 3; ++cidx) atomicAdd(row + cidx, fm * (C[0][j] * Gr[0][cidx] + C[1][j] * Gr[1][cidx] + C[2][j] * Gr[2][cidx]));
 #pragma unroll
-        for (int cidx = 0; cidx < 3; ++cidx) atomicAdd(row + 3 + cidx, C[cidx][j]);
+        for (int cidx = 0; cidx < 3; ++cidx) atomicAdd(row + 3 + cidx, fm * C[cidx][j]);
       }
       if (d.use_points) {
         double AR[3][3], U[3][3], gP[3], Wc[3][NC], Wv[3][6];
@@ -331,7 +338,7 @@ __global__ __launch_bounds__(256) void k_sweep(Dev d) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-          for (int j = 0; j < 6; ++j) wv[i * 6 + j] = Wv[i][j];
+          for (int j = 0; j < 6; ++j) wv[i * 6 + j] = fm * Wv[i][j];
       }
     }
   }

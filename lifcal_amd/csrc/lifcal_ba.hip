@@ -100,11 +100,12 @@ struct lifcal_ba_handle {
   lifcal_ba_allreduce_fn hook = nullptr; void* hook_ctx = nullptr;
   lifcal_ba_allgather_fn ghook = nullptr; void* ghook_ctx = nullptr;
   Xch xch{}; bool xch_ok = false, force_exchange = false;   // slab exchange of the reduced block (multi-GPU, no promoted points)
-  void* comm = nullptr;
+  void* comm = nullptr; bool comm_borrowed = false;   // RCCL communicator (borrowed: it belongs to another handle, see lifcal_ba_solve_windowed)
   double last_cost = 0, last_gmax = 0;
   size_t chol_lds = 0;
   double* ls_buf = nullptr;      // line search scalars, all-reduced: [0] |step|^2 [1] |x|^2 [2] grad . dir (each: this rank's points; rank 0 adds the replicated camera + pose part)
   double* dirmax_buf = nullptr;  // [0..63] per-rank max |point step| (one-hot slots, all-reduced), [64] max |reduced step| (replicated)
+  uint8_t* frame_live_dev = nullptr;   // d.frame_live (frame is observed AND its pose is free), writable copy of the pointer
   bool trace = false;            // LIFCAL_TRACE=1: one stderr line per host decision of the LM loop, tagged with the rank
   double* Lpanel = nullptr; size_t bandw_lds = 0, backw_lds = 0; bool bandw_ok = false;
   // profiling: 5 events per sweep (start, after tables, after k_sweep, before k_schur, after k_schur, end)
@@ -633,7 +634,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
     U(t, L.pass_pt0); d.pass_pt0 = t; U(t, L.pass_np); d.pass_np = t; U(t, L.pass_gid0); d.pass_gid0 = t; U(t, L.pass_ng); d.pass_ng = t;
     U(t, L.v2_points); d.v2_points = t; U(t, L.v2_ptinfo); d.v2_ptinfo = t; U(t, L.v2_passpt); d.v2_passpt = t; U(t, L.v2_gidx); d.v2_gidx = t; U(t, L.v2_slot); d.v2_slot = t; U(t, L.v2_tile_row0); d.v2_tile_row0 = t; U(t, L.v2_lens); d.v2_lens = t; }
   { double* t; U(t, L.v2_u); d.v2_u = t; U(t, L.v2_v); d.v2_v = t; }
-  if (opt.precision == 1) { float* t; U(t, L.v2_du); d.v2_du = t; U(t, L.v2_dv); d.v2_dv = t; A(d.ltf, (size_t)d.n_lenses * LENS_STRIDE); }
+  if (opt.precision == 1) { float* t; U(t, L.v2_du); d.v2_du = t; U(t, L.v2_dv); d.v2_dv = t; A(d.ltf, (size_t)d.n_lenses * LENS_STRIDE); A(d.ltw, 2 * (size_t)d.n_lenses); }
   { uint32_t *a, *b, *c; U(a, L.v2f_pt); U(b, L.v2f_fr); U(c, L.v2f_cnt);
     d.v2f_pt = a;
     h->ts2 = TileSet{L.pass_tiles() * L.n_passes, d.v2_tile_row0, a, b, c, d.v2_lens, d.v2_u, d.v2_v}; }
@@ -660,7 +661,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   h->ts1 = TileSet{d.n_tiles, d.tile_row0, d.slot_pt, d.slot_fr, d.slot_cnt, d.ell_lens, d.ell_u, d.ell_v};
   { int32_t* t; U(t, L.promoted); d.promoted = t; }
   { uint32_t* t; U(t, L.promoted_ids); d.promoted_ids = t; U(t, L.pt_slot0); d.pt_slot0 = t; U(t, L.pt_nslots); d.pt_nslots = t; U(t, L.owned_points); d.owned = t; }
-  { std::vector<uint8_t> live(L.frame_used); uint8_t* t; U(t, live); d.frame_live = t; }
+  { std::vector<uint8_t> live(L.frame_used); uint8_t* t; U(t, live); d.frame_live = t; h->frame_live_dev = t; }
   A(d.ptacc, (size_t)d.P * 36); A(d.Uinv, (size_t)d.P * 9);
   if (hipMemset(d.ptacc, 0, (size_t)std::max(1u, d.P) * 36 * sizeof(double)) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); A(d.lamP, (size_t)d.P * 3); A(d.sigP, (size_t)d.P * 3);
   A(d.Wv, (size_t)L.n_groups * 18);
@@ -727,7 +728,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
 void lifcal_ba_destroy(lifcal_ba_handle* h) {
   if (!h) return;
   if (h->stream) (void)hipStreamSynchronize(h->stream);
-  if (h->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
+  if (h->comm && !h->comm_borrowed && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -735,6 +736,17 @@ void lifcal_ba_destroy(lifcal_ba_handle* h) {
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
   if (h->stream) (void)hipStreamDestroy(h->stream);
   delete h;
+}
+
+int lifcal_ba_set_fixed_frames(lifcal_ba_handle* h, const uint8_t* fixed) {
+  if (!h) return LIFCAL_BA_ERR_INVALID_ARG;
+  if (!h->use_sweep3) { g_last_error = "lifcal_ba_set_fixed_frames needs k_sweep3 (unset LIFCAL_SWEEP_KERNEL)"; return LIFCAL_BA_ERR_INVALID_ARG; }
+  HIP_TRY(hipSetDevice(h->opt.device));
+  std::vector<uint8_t> live(h->plan.frame_used);
+  if (fixed) for (uint32_t f = 0; f < h->d.F; ++f) if (fixed[f]) live[f] = 0;
+  if (!live.empty()) HIP_TRY(hipMemcpy(h->frame_live_dev, live.data(), live.size(), hipMemcpyHostToDevice));
+  h->sigma_valid = false;   // the Jacobi scaling is fixed at the first sweep of a solve: a new column set starts a new solve
+  return 0;
 }
 
 int lifcal_ba_upload_parameters(lifcal_ba_handle* h) { return h ? upload_parameters(h) : LIFCAL_BA_ERR_INVALID_ARG; }
@@ -1126,3 +1138,6 @@ int lifcal_ba_project_observations(lifcal_ba_handle* h, double* x_proj, double* 
 
 // COLMAP sparse-model ingestion (include/lifcal_colmap.h)
 #include "colmap.hpp"
+
+// frame-windowed solve for long sequences (include/lifcal_ba.h)
+#include "windowed.hpp"

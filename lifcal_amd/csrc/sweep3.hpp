@@ -157,12 +157,14 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
   uint32_t* hw_written = (uint32_t*)(misc + 4) + wl;       // steps the evaluator has published
   uint32_t* hw_read = (uint32_t*)(misc + 4) + 4 + wl;      // steps the accumulator has taken
   uint32_t* eval_done = (uint32_t*)(misc + 3);             // evaluator waves that have finished the emission of a pass (monotone)
+  // acquire / release at workgroup scope: the consumer's reads of the hand-off buffer may not be hoisted above the wait, the
+  // producer's writes may not sink below the publish (on gfx950 both order LDS through lgkmcnt; no cache maintenance is involved)
   auto wait_for = [](uint32_t* flag, uint32_t need) {
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < need) __builtin_amdgcn_s_sleep(2);
   };
   auto publish = [](uint32_t* flag, uint32_t value) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the wave's LDS traffic of this step is done before the counter moves
-    __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
 
   // Schur product: 4x4 micro-tiles over the lower triangle, software-pipelined.  With one tile per thread (ntri <= 256) the
@@ -298,14 +300,17 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
       // compiler copy freshly loaded registers at the back-edge, i.e. wait for the loads it has just issued.
       ET ua = 0, va = 0, ub = 0, vb = 0; uint32_t lb = 0, la = 0;
       ET Ln[LENS_STRIDE];
+      double wn0 = 0.0, wn1 = 0.0;   // F32: w of the lens in fp64 (side table), prefetched with the row
 #pragma unroll
       for (int i = 0; i < LENS_STRIDE; ++i) Ln[i] = 0;
       if (kmax > 0) {
         const size_t at = (size_t)row0 * 64 + lane;
         ua = obs_u[at]; va = obs_v[at];
-        const ET* L = lens_tab + (size_t)d.v2_lens[at] * LENS_STRIDE;
+        const uint32_t l0 = d.v2_lens[at];
+        const ET* L = lens_tab + (size_t)l0 * LENS_STRIDE;
 #pragma unroll
         for (int i = 0; i < LENS_STRIDE; ++i) Ln[i] = L[i];
+        if constexpr (F32) { wn0 = d.ltw[2 * (size_t)l0]; wn1 = d.ltw[2 * (size_t)l0 + 1]; }
         const size_t at2 = ((size_t)row0 + (kmax > 1 ? 1u : 0u)) * 64 + lane;
         ub = obs_u[at2]; vb = obs_v[at2]; lb = d.v2_lens[at2];
       }
@@ -324,7 +329,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
           for (int i = 0; i < LENS_STRIDE; ++i) L[i] = Ln[i];
           ET r[2], Jq[2][3], Jc[2][NC];
           ET arg;
-          if constexpr (F32) obs_eval2f<NR, TAN, ADJ>(cf, gcn, L, u, v, d.robust != 0, r, Jq, Jc, arg);
+          if constexpr (F32) obs_eval2f<NR, TAN, ADJ>(cf, gcn, L, wn0, wn1, u, v, d.robust != 0, r, Jq, Jc, arg);
           else obs_eval2<NR, TAN, ADJ>(c, gcn, L, u, v, d.robust != 0, r, Jq, Jc, arg);
           // hand-off to the accumulator wave, [value][lane]
 #pragma unroll
@@ -349,6 +354,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
           const ET* Lp = lens_tab + (size_t)ln * LENS_STRIDE;
 #pragma unroll
           for (int i = 0; i < LENS_STRIDE; ++i) Ln[i] = Lp[i];
+          if constexpr (F32) { wn0 = d.ltw[2 * (size_t)ln]; wn1 = d.ltw[2 * (size_t)ln + 1]; }
           const uint32_t kk = (k + 2 < kmax) ? k + 2 : kmax - 1;
           const size_t at = ((size_t)row0 + kk) * 64 + lane;
           uc = obs_u[at]; vc = obs_v[at]; lc = d.v2_lens[at];
@@ -381,7 +387,9 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < 3; ++j) GAG[i][j] = Gr[0][i] * AG[0][j] + Gr[1][i] * AG[1][j] + Gr[2][i] * AG[2][j];
-        const RunMask rm = run_masks(cnt, lf);
+        RunMask rm = run_masks(cnt, lf);
+        const bool fpose = d.frame_live[fr] != 0;   // 0: the pose of this frame is held constant (lifcal_ba_set_fixed_frames): no pose columns
+        rm.head = rm.head && fpose;
         double* fr_acc = Fr + lf;
         {
           int vi = 0;
@@ -424,9 +432,9 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
             atomicAdd(acc + 6 + i, R[i] * bv[0] + R[3 + i] * bv[1] + R[6 + i] * bv[2]);
             double* zrow = Zd + (size_t)(3 * lp + i) * zs;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const double wij = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j]; atomicAdd(zrow + 6 * lf + j, wij); }
+            for (int j = 0; j < 3; ++j) { const double wij = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j]; if (fpose) atomicAdd(zrow + 6 * lf + j, wij); }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const double wij = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j]; atomicAdd(zrow + 6 * lf + 3 + j, wij); }
+            for (int j = 0; j < 3; ++j) { const double wij = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j]; if (fpose) atomicAdd(zrow + 6 * lf + 3 + j, wij); }
           }
         }
       }
@@ -598,7 +606,8 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < NC; ++j) C[i][j] *= c.chm[j];   // sign/scale folding and free-column mask, once per lane
-        const RunMask rm = run_masks(cnt, lf);
+        RunMask rm = run_masks(cnt, lf);
+        rm.head = rm.head && d.frame_live[flo + lf] != 0;   // constant pose: no camera x pose block
         double* fr_acc = Fr + lf;
 #pragma unroll
         for (int j = 0; j < NC; ++j) {

@@ -1,0 +1,85 @@
+// windowed.hpp — lifcal_ba_solve_windowed: frame-windowed ("streaming") bundle adjustment for long sequences
+// (include/lifcal_ba.h; BASELINE configs[4]: recalib, 2000 frames, pose + point refinement).  Host code; included at the end of
+// lifcal_ba.hip.  No reference counterpart ("Config 5's streaming has no reference counterpart; implement as the same
+// sharding over a sliding window of frames"): every window is an ordinary lifcal_ba problem — same kernels, same point sharding
+// across ranks — built from the window's frames and the points they observe; only one window is resident on the device.
+#pragma once
+#include <algorithm>
+#include <vector>
+
+extern "C" int lifcal_ba_solve_windowed(const lifcal_ba_problem* p, const lifcal_ba_options* o, uint32_t window_frames, uint32_t overlap_frames,
+                                        lifcal_ba_handle* comm_template, lifcal_ba_window_report* per_window, uint32_t* n_windows) {
+  if (!p || !n_windows || window_frames == 0 || overlap_frames >= window_frames) return LIFCAL_BA_ERR_INVALID_ARG;
+  if (int rc = lifcal::plan_validate(p)) return rc;
+  lifcal_ba_options opt; if (o) opt = *o; else lifcal_ba_default_options(&opt);
+  if (opt.world_size > 1 && !comm_template) { g_last_error = "lifcal_ba_solve_windowed: world_size > 1 needs a handle carrying the collectives"; return LIFCAL_BA_ERR_INVALID_ARG; }
+  const uint32_t F = p->n_frames, N = p->n_obs, P = p->n_points;
+  const uint32_t capacity = per_window ? *n_windows : 0;
+  *n_windows = 0;
+  // observations by frame (counting sort: input order is kept inside a frame)
+  std::vector<uint32_t> f0(F + 1, 0), by_frame(N);
+  for (uint32_t i = 0; i < N; ++i) ++f0[p->fr[i] + 1];
+  for (uint32_t f = 0; f < F; ++f) f0[f + 1] += f0[f];
+  { std::vector<uint32_t> fill(f0.begin(), f0.end() - 1); for (uint32_t i = 0; i < N; ++i) by_frame[fill[p->fr[i]]++] = i; }
+  const uint32_t step = window_frames - overlap_frames;
+  std::vector<int32_t> local_of(P, -1);
+  uint32_t widx = 0;
+  for (uint32_t a = 0; a < F; a += step, ++widx) {
+    const uint32_t b = std::min(F, a + window_frames);
+    const uint32_t nf = b - a, n = f0[b] - f0[a];
+    // the window's points, in ascending global id
+    std::vector<uint32_t> pts_ids;
+    for (uint32_t k = f0[a]; k < f0[b]; ++k) { const uint32_t q = p->pt[by_frame[k]]; if (local_of[q] < 0) { local_of[q] = 0; pts_ids.push_back(q); } }
+    std::sort(pts_ids.begin(), pts_ids.end());
+    for (uint32_t j = 0; j < pts_ids.size(); ++j) local_of[pts_ids[j]] = (int32_t)j;
+    std::vector<double> u(n), v(n), mcx(n), mcy(n), pts(3 * pts_ids.size());
+    std::vector<uint32_t> pt(n), fr(n);
+    for (uint32_t k = 0; k < n; ++k) {
+      const uint32_t i = by_frame[f0[a] + k];
+      u[k] = p->u[i]; v[k] = p->v[i]; mcx[k] = p->mcx[i]; mcy[k] = p->mcy[i];
+      pt[k] = (uint32_t)local_of[p->pt[i]]; fr[k] = p->fr[i] - a;
+    }
+    for (size_t j = 0; j < pts_ids.size(); ++j) for (int c = 0; c < 3; ++c) pts[3 * j + c] = p->pts[3 * (size_t)pts_ids[j] + c];
+    // distance constraints whose two points both belong to the window
+    std::vector<uint32_t> ci, cj; std::vector<double> cd, cs;
+    if (p->use_constraints && p->n_constraints && p->c_i && p->c_j)
+      for (uint32_t c = 0; c < p->n_constraints; ++c)
+        if (local_of[p->c_i[c]] >= 0 && local_of[p->c_j[c]] >= 0) { ci.push_back((uint32_t)local_of[p->c_i[c]]); cj.push_back((uint32_t)local_of[p->c_j[c]]); cd.push_back(p->c_dist[c]); cs.push_back(p->c_sigma[c]); }
+    lifcal_ba_problem sub = *p;
+    sub.n_obs = n; sub.n_frames = nf; sub.n_points = (uint32_t)pts_ids.size(); sub.n_constraints = (uint32_t)ci.size();
+    sub.u = u.data(); sub.v = v.data(); sub.mcx = mcx.data(); sub.mcy = mcy.data(); sub.pt = pt.data(); sub.fr = fr.data();
+    sub.views = p->views + 6 * (size_t)a;    // in place: the caller's poses of this window
+    sub.pts = pts.data();
+    sub.c_i = ci.empty() ? nullptr : ci.data(); sub.c_j = cj.empty() ? nullptr : cj.data();
+    sub.c_dist = cd.empty() ? nullptr : cd.data(); sub.c_sigma = cs.empty() ? nullptr : cs.data();
+    lifcal_ba_window_report rep{};
+    rep.first_frame = a; rep.n_frames = nf; rep.n_points = sub.n_points; rep.n_obs = n;
+    int rc = 0;
+    if (n > 0) {
+      lifcal_ba_handle* h = nullptr;
+      rc = lifcal_ba_create(&sub, &opt, &h);
+      if (rc == 0) {
+        if (comm_template) {   // the collectives of the caller's handle serve every window (the communicator stays the caller's)
+          h->hook = comm_template->hook; h->hook_ctx = comm_template->hook_ctx;
+          h->ghook = comm_template->ghook; h->ghook_ctx = comm_template->ghook_ctx;
+          h->comm = comm_template->comm; h->comm_borrowed = true;
+        }
+        if (widx > 0 && overlap_frames > 0) {   // poses the previous window has refined stay as they are
+          std::vector<uint8_t> fixed(nf, 0);
+          for (uint32_t f = 0; f < std::min(nf, overlap_frames); ++f) fixed[f] = 1;
+          rep.n_fixed_frames = std::min(nf, overlap_frames);
+          rc = lifcal_ba_set_fixed_frames(h, fixed.data());
+        }
+        if (rc == 0) rc = lifcal_ba_solve(h, &rep.summary);
+        lifcal_ba_destroy(h);
+      }
+      if (rc == 0) for (size_t j = 0; j < pts_ids.size(); ++j) for (int c = 0; c < 3; ++c) p->pts[3 * (size_t)pts_ids[j] + c] = pts[3 * j + c];
+    }
+    for (uint32_t q : pts_ids) local_of[q] = -1;
+    if (rc) return rc;
+    if (per_window && widx < capacity) per_window[widx] = rep;
+    *n_windows = widx + 1;
+    if (b == F) break;
+  }
+  return 0;
+}

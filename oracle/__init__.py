@@ -66,6 +66,17 @@ def init_plenoptic(arrs: capi.InitArrays) -> capi.InitResult:
     return res
 
 
+def set_fixed_frames(mask=None):
+    """poses held constant in the following sweeps / solves (None clears); mirrors lifcal_ba_set_fixed_frames"""
+    L = lib()
+    L.lo_set_fixed_frames.argtypes = [C.POINTER(C.c_uint8), C.c_uint32]
+    if mask is None:
+        L.lo_set_fixed_frames(None, 0)
+    else:
+        m = np.ascontiguousarray(mask, np.uint8)
+        L.lo_set_fixed_frames(m.ctypes.data_as(C.POINTER(C.c_uint8)), len(m))
+
+
 def hardware_threads() -> int:
     return int(lib().lo_hardware_threads())
 

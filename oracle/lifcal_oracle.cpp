@@ -62,6 +62,10 @@ double now_s() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// frames whose pose is held constant (lo_set_fixed_frames; mirrors lifcal_ba_set_fixed_frames): ceres SetParameterBlockConstant on
+// views + 6 f — the residual blocks of that frame stay, their pose Jacobian does not exist.  Test-infrastructure global.
+std::vector<uint8_t> g_fixed_frames;
+
 // ---------------------------------------------------------------------------------------------
 // Problem structure
 // ---------------------------------------------------------------------------------------------
@@ -76,7 +80,7 @@ struct Structure {
   std::vector<uint8_t> cam_free;    // 17: column takes part in the solve
   std::vector<int> pt_begin, pt_obs;  // CSR point -> observation indices (input order)
   std::vector<std::vector<int>> pt_cons;  // constraints touching each point
-  std::vector<uint8_t> pt_used, fr_used;
+  std::vector<uint8_t> pt_used, fr_used, fr_fixed;
 
   explicit Structure(const lifcal_ba_problem* pr) : p(pr), cfg(pr->config) {
     F = pr->n_frames; P = pr->n_points; N = pr->n_obs; M = pr->n_constraints;
@@ -97,6 +101,8 @@ struct Structure {
     pt_begin.assign(P + 1, 0);
     pt_used.assign(P, 0); fr_used.assign(F, 0);
     for (int i = 0; i < N; ++i) { pt_begin[pr->pt[i] + 1]++; pt_used[pr->pt[i]] = 1; fr_used[pr->fr[i]] = 1; }
+    fr_fixed.assign(F, 0);
+    for (int f = 0; f < F && f < (int)g_fixed_frames.size(); ++f) if (g_fixed_frames[f]) { fr_fixed[f] = 1; fr_used[f] = 0; }   // constant pose: not a column
     for (int i = 0; i < P; ++i) pt_begin[i + 1] += pt_begin[i];
     pt_obs.resize(N);
     std::vector<int> fill(pt_begin.begin(), pt_begin.end() - 1);
@@ -249,6 +255,7 @@ double evaluate(const Structure& s, const double* cam, const double* views, cons
       } else {
         eval_obs(s, (int)i, cam, views, pts, jac, r, Jc, Jv, Jp);
       }
+      if (jac && s.use_poses && s.fr_fixed[s.p->fr[i]]) for (int k = 0; k < 12; ++k) Jv[k] = 0.0;   // constant pose
       const double sq = r[0] * r[0] + r[1] * r[1];
       if (s.cfg.robust) {
         double rho0, rho1; cauchy(loss_scale, sq, rho0, rho1);
@@ -804,6 +811,12 @@ int lo_constraint_block(const double p1[3], const double p2[3], double distance,
   Jet<6> res = lo::distance_constraint<Jet<6>>(a, b, distance, sigma);
   *r = res.a;
   if (J) for (int k = 0; k < 6; ++k) J[k] = res.v[k];
+  return 0;
+}
+
+int lo_set_fixed_frames(const uint8_t* fixed, uint32_t n_frames) {
+  g_fixed_frames.clear();
+  if (fixed) g_fixed_frames.assign(fixed, fixed + n_frames);
   return 0;
 }
 

@@ -15,6 +15,8 @@ int lo_residual_block(uint32_t config, int arity, const double cam[17], const do
                       double u, double v, double mcx, double mcy, double spx, double spy, double scale,
                       double r[2], double J[52]);
 int lo_constraint_block(const double p1[3], const double p2[3], double distance, double sigma, double* r, double J[6]);
+/* frames whose pose is held constant in every following lo_sweep / lo_solve (NULL or n_frames = 0 clears): mirrors lifcal_ba_set_fixed_frames */
+int lo_set_fixed_frames(const uint8_t* fixed, uint32_t n_frames);
 int lo_cost(const lifcal_ba_problem* p, double loss_scale, int threads, double* cost);
 int lo_residuals(const lifcal_ba_problem* p, double* r2n);
 int lo_reduced_size(const lifcal_ba_problem* p, uint32_t* n_reduced, uint32_t* n_promoted);

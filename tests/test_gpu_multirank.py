@@ -30,6 +30,7 @@ def _worker(rank, world, port, out_dir, spec_kw, mode):
         pa = mk()
     else:
         spec_kw = dict(spec_kw); bounded = spec_kw.pop("bounded", False)
+        window_args = {k: spec_kw.pop(k) for k in ("_window", "_overlap") if k in spec_kw}
         sc = scene.make_scene(scene.SceneSpec(**spec_kw))
         if bounded:
             from tests.helpers import bounded_problem
@@ -37,6 +38,11 @@ def _worker(rank, world, port, out_dir, spec_kw, mode):
         else:
             pa = capi.ProblemArrays.from_scene(sc)
     o = capi.default_options_py(); o.rank = rank; o.world_size = world
+    if mode == "windowed":
+        spec_kw = dict(spec_kw, **window_args)
+        live = 5 + (sc.config & 3) + (2 if sc.config & 4 else 0)   # BASELINE configs[4]: intrinsics constant, poses + points refined
+        pa = capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, sc.cam_gt.copy(), sc.views0.copy(), sc.pts0.copy(), sc.spx, sc.scale, sc.config,
+                                fixed_mask=(1 << live) - 1, use_constraints=0)
     ba = BundleAdjustment(pa, o)
 
     def hook(ptr, count, stream):
@@ -60,8 +66,18 @@ def _worker(rank, world, port, out_dir, spec_kw, mode):
         hip.hipMemcpy(recv, allb.ctypes.data, world * count * 8, 1)
         calls["gather"] += 1; calls["gather_doubles"] = count
         return 0
-    if mode == "allgather":
+    if mode in ("allgather", "windowed"):
         ba.set_allgather(ghook)
+    if mode == "windowed":   # lifcal_ba_solve_windowed with this handle's collectives: every window sharded over the ranks
+        from lifcal_amd import performBundleAdjustmentWindowed
+        reps = performBundleAdjustmentWindowed(pa, spec_kw["_window"], spec_kw["_overlap"], options=o, comm_template=ba)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), cam=pa.cam, views=pa.views, pts=pa.pts,
+                 it=np.array([r.summary.iterations for r in reps]), term=np.array([r.summary.termination for r in reps]),
+                 first=np.array([r.first_frame for r in reps]), gather_calls=calls["gather"])
+        ba.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     sw = ba.sweep(1e4, want_matrices=(rank == 0))
     summ = ba.performBundleAdjustment()
     st = ba.calcReprojectionError()
@@ -175,3 +191,26 @@ def test_bounded_problems_backtrack_in_lockstep(built, tmp_path, spec_kw, world)
         assert abs(float(rr["final"]) - so.final_cost) <= 1e-8 * so.final_cost
         assert np.allclose(rr["cam"][:5], pb.cam[:5], rtol=1e-6)
         assert np.array_equal(rr["cam"], rs[0]["cam"]) and np.array_equal(rr["views"], rs[0]["views"]) and np.array_equal(rr["pts"], rs[0]["pts"])
+
+
+def test_windowed_driver_on_two_ranks(built, tmp_path):
+    """lifcal_ba_solve_windowed at world size 2 (the shape of BASELINE configs[4]: frame windows, each sharded by 3D point over the
+    ranks, collectives of the caller's handle): both ranks end with the single-process result"""
+    from lifcal_amd import _capi as capi, scene, performBundleAdjustmentWindowed
+    from tests.helpers import free_port
+    spec_kw = dict(n_frames=48, n_points=300, window=8, config=0xF06, seed=1450, outlier_fraction=0.02, _window=20, _overlap=6)
+    mp.spawn(_worker, args=(2, free_port(), str(tmp_path), spec_kw, "windowed"), nprocs=2, join=True)
+    kw = {k: v for k, v in spec_kw.items() if not k.startswith("_")}
+    sc = scene.make_scene(scene.SceneSpec(**kw))
+    live = 5 + (sc.config & 3) + (2 if sc.config & 4 else 0)
+    pa = capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, sc.cam_gt.copy(), sc.views0.copy(), sc.pts0.copy(), sc.spx, sc.scale, sc.config,
+                            fixed_mask=(1 << live) - 1, use_constraints=0)
+    reps = performBundleAdjustmentWindowed(pa, 20, 6)
+    r0 = np.load(os.path.join(str(tmp_path), "rank0.npz")); r1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+    assert int(r0["gather_calls"]) > 0
+    for r in (r0, r1):
+        assert list(r["first"]) == [w.first_frame for w in reps] and list(r["it"]) == [w.summary.iterations for w in reps]
+        assert list(r["term"]) == [w.summary.termination for w in reps]
+        assert np.allclose(r["views"], pa.views, rtol=0, atol=1e-6 * (1 + np.abs(pa.views).max()))
+        assert np.allclose(r["pts"], pa.pts, rtol=0, atol=1e-6 * (1 + np.abs(pa.pts).max()))
+    assert np.array_equal(r0["views"], r1["views"]) and np.array_equal(r0["pts"], r1["pts"])
