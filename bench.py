@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--precision", type=int, choices=[0, 1], default=0,
                     help="0: fp64 everywhere (the BASELINE metric configuration); 1: options.precision = 1, residual / Jacobian of an observation in fp32 "
                          "(fp32 observation words + fp32 lens table), all accumulation and the solve in fp64 (BASELINE configs[4]'s arithmetic)")
+    ap.add_argument("--deterministic", action="store_true", help="options.deterministic = 1: ordered reductions, bitwise reproducible (slower)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the full LM solve after the timed sweeps (profiling runs: only sweep kernels in the trace)")
     ap.add_argument("--comm", choices=["rccl", "gloo"], default="rccl",
@@ -188,6 +189,7 @@ def main():
     o.rank = rank
     o.world_size = world
     o.precision = args.precision
+    o.deterministic = 1 if args.deterministic else 0
     t_create = time.perf_counter()
     ba = BundleAdjustment(pa, o)
     t_create = time.perf_counter() - t_create   # planner (host) + upload: once per problem, outside the metric
@@ -334,7 +336,8 @@ def main():
             "config": {"lens_selection": "reference generator (lifcal_mla_project)" if use_web else "K-nearest stand-in",
                        "workload": f"{args.workload}: {F_tot} frames, {P_tot} points, {n_obs_total} micro-image observations, "
                                    f"window {spec.window}, config {spec.config:#x} (2 radial + tangential, mlCenterAdj, Cauchy(0.5), refine poses+points)",
-                       "obs_per_gpu": n_loc, "n_reduced": n_red, "sharding": "by 3D point" if world > 1 else "single GPU", "comm": comm_used},
+                       "obs_per_gpu": n_loc, "n_reduced": n_red, "sharding": "by 3D point" if world > 1 else "single GPU", "comm": comm_used,
+                       "deterministic": bool(args.deterministic)},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (residual+Jacobian+block accumulation)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
                          "traffic": load_traffic(args.workload)[0], "traffic_source": load_traffic(args.workload)[1],

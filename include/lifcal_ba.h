@@ -122,7 +122,9 @@ typedef struct lifcal_ba_options {
   int32_t rank;                 /* this process' rank in the point-sharded job (0 if single GPU) */
   int32_t world_size;           /* number of ranks (1 if single GPU) */
   int32_t verbose;              /* 1: print Ceres-style per-iteration table to stdout (:957) */
-  int32_t deterministic;        /* 1 (ordered slab reduction instead of f64 atomics): NOT YET IMPLEMENTED, create() rejects it */
+  int32_t deterministic;        /* 1: bitwise reproducible results — LDS accumulation in wave order, per-block window slabs summed in block order
+                                   instead of the cross-block f64 atomics, value kernels summed per workgroup in order.  Supported for
+                                   the <2,17,6,3> arity without constraints / bounds / oversized groups; create() rejects the rest.      */
 } lifcal_ba_options;
 
 typedef struct lifcal_ba_summary {

@@ -70,6 +70,10 @@ struct Dev {
   const float *v2_du, *v2_dv;    // options.precision = 1: observation relative to its micro-lens centre (u - mcx, v - mcy), fp32
   float* ltf;                    // options.precision = 1: fp32 lens table of the CURRENT point (see lens_row_to_float)
   double* ltw;                   // ... and w = (a) c_u of every lens in fp64 (2 per lens): the one fp64 operand of the fp32 evaluation
+  // options.deterministic = 1: per-block slabs of the LDS windows (k_det_reduce sums them in block order), per-workgroup slots
+  // of the value-only kernels (k_det_sum)
+  uint32_t deterministic, det_stride;
+  double *det_slab, *det_slots;
   const uint32_t* special_owned;
   // constraints
   const uint32_t *c_i, *c_j, *my_cons, *pt_cons0, *pt_cons_list; const double *c_dist, *c_sigma;
@@ -661,6 +665,96 @@ __global__ void k_xch_unpack(Dev d, Xch x) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// options.deterministic = 1: ordered reduction of the per-block window slabs k_sweep3 leaves in HBM (instead of its atomic
+// flush).  One thread owns one entry of the reduced block and adds the contributions of the blocks whose frame window covers
+// it, in ascending block order: bitwise reproducible, no atomics.  Blocks are in point order, i.e. in non-decreasing first
+// frame, and a window spans at most Plan::NF_MAX frames, so the covering blocks of a frame are one short run.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_det_reduce(Dev d, int mode) {
+  const V2Lds lay(d.v2_nfmax, true, 256);
+  const uint32_t NFm = lay.nfm, vlen = 6 * NFm + NCMAX + 3, NC = d.nc, NCC = NC * (NC + 1) / 2;
+  const uint32_t F = d.F, F6 = 6 * F, BS = (d.bw + 1) * 36, nB = d.n_blocks;
+  const uint64_t n1 = (uint64_t)F * BS, n2 = n1 + (uint64_t)NC * F6, n3 = n2 + NCC, n4 = n3 + 3ull * F6, n5 = n4 + 3ull * NC, n6 = n5 + 3;
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n6) return;
+  const uint32_t camrow = 3 * d.Q, camcol = F6 + 3 * d.Q;
+  // blocks whose window [flo, flo + nf) contains the frames fa <= fb: first / last candidate by first frame
+  auto covering = [&](uint32_t fa, uint32_t fb, uint32_t& b0, uint32_t& b1) {
+    uint32_t lo = 0, hi = nB;                       // first block with flo > fa
+    while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (d.blk_flo[m] <= fa) lo = m + 1; else hi = m; }
+    b1 = lo;                                        // candidates end here (exclusive)
+    b0 = b1;
+    while (b0 > 0 && d.blk_flo[b0 - 1] + 20u > fb) --b0;   // Plan::NF_MAX = 20
+  };
+  double sum = 0.0;
+  double* dst = nullptr;
+  if (t < n1) {                                     // pose x pose band
+    if (mode != 0) return;
+    const uint32_t f = (uint32_t)(t / BS), r = (uint32_t)(t % BS), dd = r / 36, e = r % 36;
+    if (dd > f || (dd == 0 && (e % 6) > (e / 6))) return;
+    uint32_t b0, b1; covering(f - dd, f, b0, b1);
+    for (uint32_t b = b0; b < b1; ++b) {
+      const uint32_t flo = d.blk_flo[b], nf = d.blk_nf[b];
+      if (f >= flo + nf) continue;
+      const uint32_t lf = f - flo, lj = f - dd - flo;
+      sum += d.det_slab[(size_t)b * d.det_stride + (size_t)(lf * (lf + 1) / 2 + lj) * 36 + e];
+    }
+    dst = d.Sband + t;
+  } else if (t < n2) {                              // camera x pose
+    if (mode != 0) return;
+    const uint32_t q = (uint32_t)(t - n1), j = q / F6, col = q % F6, f = col / 6;
+    uint32_t b0, b1; covering(f, f, b0, b1);
+    for (uint32_t b = b0; b < b1; ++b) {
+      const uint32_t flo = d.blk_flo[b], nf = d.blk_nf[b];
+      if (f >= flo + nf) continue;
+      sum += d.det_slab[(size_t)b * d.det_stride + lay.off_cp + (size_t)j * 6 * NFm + 6 * (f - flo) + col % 6];
+    }
+    dst = d.Sarrow + (size_t)(camrow + j) * d.ld + col;
+  } else if (t < n3) {                              // camera x camera
+    if (mode != 0) return;
+    const uint32_t q = (uint32_t)(t - n2);
+    for (uint32_t b = 0; b < nB; ++b) sum += d.det_slab[(size_t)b * d.det_stride + lay.off_cc + q];
+    uint32_t i = 0; while ((i + 1) * (i + 2) / 2 <= q) ++i;
+    dst = d.Sarrow + (size_t)(camrow + i) * d.ld + camcol + (q - i * (i + 1) / 2);
+  } else if (t < n4) {                              // gB | hdiag | rhs, pose part
+    const uint32_t q = (uint32_t)(t - n3), w = q / F6, col = q % F6, f = col / 6;
+    if (mode != 0 && w != 1) return;
+    uint32_t b0, b1; covering(f, f, b0, b1);
+    for (uint32_t b = b0; b < b1; ++b) {
+      const uint32_t flo = d.blk_flo[b], nf = d.blk_nf[b];
+      if (f >= flo + nf) continue;
+      sum += d.det_slab[(size_t)b * d.det_stride + lay.off_vec + (size_t)w * vlen + 6 * (f - flo) + col % 6];
+    }
+    dst = (w == 0 ? d.gB : (w == 1 ? d.hdiag : d.rhsacc)) + col;
+  } else if (t < n5) {                              // ... camera part
+    const uint32_t q = (uint32_t)(t - n4), w = q / NC, j = q % NC;
+    if (mode != 0 && w != 1) return;
+    for (uint32_t b = 0; b < nB; ++b) sum += d.det_slab[(size_t)b * d.det_stride + lay.off_vec + (size_t)w * vlen + 6 * NFm + j];
+    dst = (w == 0 ? d.gB : (w == 1 ? d.hdiag : d.rhsacc)) + camcol + j;
+  } else {                                          // cost, bad-U count, max |g_p|
+    if (mode != 0) return;
+    const uint32_t q = (uint32_t)(t - n5);
+    if (q < 2) { for (uint32_t b = 0; b < nB; ++b) sum += d.det_slab[(size_t)b * d.det_stride + lay.off_fr + q]; dst = d.scal + (q == 0 ? SCAL_COST : SCAL_BAD_U); }
+    else {
+      double m = 0.0;
+      for (uint32_t b = 0; b < nB; ++b) m = fmax(m, d.det_slab[(size_t)b * d.det_stride + lay.off_fr + 2]);
+      d.scal[SCAL_GMAX0 + d.rank] = fmax(d.scal[SCAL_GMAX0 + d.rank], m);
+      return;
+    }
+  }
+  *dst += sum;
+}
+
+// per-workgroup partial sums of the value-only kernels, added up in workgroup order (options.deterministic)
+__global__ void k_det_sum(const double* slots, uint32_t n_wg, uint32_t K, double* dst) {
+  const uint32_t k = threadIdx.x;
+  if (k >= K) return;
+  double s = 0.0;
+  for (uint32_t g = 0; g < n_wg; ++g) s += slots[(size_t)g * K + k];
+  dst[k] += s;
+}
+
+// ---------------------------------------------------------------------------------------------
 // finalize: LM diagonal on the reduced system + rhs row; identity on columns that are not solved for
 // ---------------------------------------------------------------------------------------------
 __global__ void k_finalize(Dev d, double radius) {
@@ -946,7 +1040,11 @@ __global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by th
   const uint32_t wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
   if ((threadIdx.x & 63) == 0) { part[wv][0] = gtd; part[wv][1] = ddd; part[wv][2] = st2; part[wv][3] = x2; }
   __syncthreads();
-  if (threadIdx.x < 4) { double t = 0.0; for (uint32_t k = 0; k < nwv; ++k) t += part[k][threadIdx.x]; atomicAdd(partial + threadIdx.x, t); }
+  if (threadIdx.x < 4) {
+    double t = 0.0; for (uint32_t k = 0; k < nwv; ++k) t += part[k][threadIdx.x];
+    if (d.deterministic) d.det_slots[(size_t)blockIdx.x * 4 + threadIdx.x] = t;   // k_det_sum adds the workgroups up in order
+    else atomicAdd(partial + threadIdx.x, t);
+  }
 }
 
 // candidate = Plus(x, t * delta) for an arbitrary step length t (ceres ParameterBlock::Plus incl. box projection), from
@@ -1067,7 +1165,10 @@ __global__ __launch_bounds__(256) void k_cost(Dev d, TileSet ts, const CamConsts
   cost = wave_sum(cost);
   if (lane == 0) part[threadIdx.x >> 6] = cost;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(cost_out, part[0] + part[1] + part[2] + part[3]);
+  if (threadIdx.x == 0) {
+    if (d.deterministic) d.det_slots[blockIdx.x] = part[0] + part[1] + part[2] + part[3];   // k_det_sum adds the workgroups up in order
+    else atomicAdd(cost_out, part[0] + part[1] + part[2] + part[3]);
+  }
 }
 
 // projected micro-image coordinates of every observation at the stored parameters, scattered back to the caller's
@@ -1145,8 +1246,11 @@ __global__ __launch_bounds__(256) void k_stats(Dev d, TileSet ts, const CamConst
   __shared__ double part[4][6];
   if (lane == 0) { double* q = part[threadIdx.x >> 6]; q[0] = sx; q[1] = sy; q[2] = n; q[3] = inl; q[4] = mx; q[5] = my; }
   __syncthreads();
-  if (threadIdx.x < 4) atomicAdd(sums + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
-  else if (threadIdx.x < 6) {
+  if (threadIdx.x < 4) {
+    const double t = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+    if (d.deterministic) d.det_slots[(size_t)blockIdx.x * 4 + threadIdx.x] = t;   // k_det_sum adds the workgroups up in order
+    else atomicAdd(sums + threadIdx.x, t);
+  } else if (threadIdx.x < 6) {
     const int k = threadIdx.x;
     atomicMax(maxbits + (k - 4), (unsigned long long)__double_as_longlong(fmax(fmax(part[0][k], part[1][k]), fmax(part[2][k], part[3][k]))));
   }

@@ -220,6 +220,13 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
     else if (h->use_sweep3 && h->sweep_waves == 2) DISPATCH_CFG(h, CALL_SWEEP3H); else if (h->use_sweep3) DISPATCH_CFG(h, CALL_SWEEP3); else DISPATCH_CFG(h, CALL_SWEEP2);
 #undef CALL_SWEEP3H
 #undef CALL_SWEEP3F
+    if (d.deterministic) {   // ordered sum of the per-block window slabs instead of the kernel's atomic flush
+      const V2Lds lay(d.v2_nfmax, true, 256);
+      (void)lay;
+      const uint32_t NCd = d.nc, F6 = 6 * d.F;
+      const uint64_t n = (uint64_t)d.F * (d.bw + 1) * 36 + (uint64_t)NCd * F6 + NCd * (NCd + 1) / 2 + 3ull * F6 + 3ull * NCd + 3;
+      hipLaunchKernelGGL(k_det_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d, mode);
+    }
 #undef CALL_SWEEP3
 #undef CALL_SWEEP2
   }
@@ -302,7 +309,10 @@ int launch_candidate(lifcal_ba_handle* h) {
   Dev& d = h->d;
   hipLaunchKernelGGL(k_update_reduced, dim3(1), dim3(256), 0, h->stream, d, h->partial);
   const uint32_t n = std::max(d.n_owned, d.Q);
-  if (d.use_points && n) hipLaunchKernelGGL(k_backsub, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, h->partial);
+  if (d.use_points && n) {
+    hipLaunchKernelGGL(k_backsub, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, h->partial);
+    if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, (n + 255) / 256, 4u, h->partial);
+  }
   HIP_TRY(hipGetLastError());
   if (int rc = launch_tables(h, d.cam_c, d.views_c, d.camc_c, d.ft_c, d.lt_c, false, true)) return rc;
   const double* pts_eval = d.use_points ? d.pts_c : d.pts;
@@ -312,6 +322,7 @@ int launch_candidate(lifcal_ba_handle* h) {
 #define CALL_COST(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)d.camc_c, (const double*)d.ft_c, (const double*)d.lt_c, pts_eval, h->partial + 4)
     DISPATCH_CFG(h, CALL_COST);
 #undef CALL_COST
+    if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, grid, 1u, h->partial + 4);
   }
   if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
   HIP_TRY(hipGetLastError());
@@ -331,6 +342,7 @@ int cost64_current(lifcal_ba_handle* h, double* cost) {
 #define CALL_COST0(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)d.camc, (const double*)d.ft, (const double*)d.lt, pts_eval, h->partial + 4)
     DISPATCH_CFG(h, CALL_COST0);
 #undef CALL_COST0
+    if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, grid, 1u, h->partial + 4);
   }
   if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
   HIP_TRY(hipGetLastError());
@@ -559,10 +571,8 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   *out = nullptr;
   lifcal_ba_options opt; if (o) opt = *o; else lifcal_ba_default_options(&opt);
   if (opt.world_size < 1 || opt.world_size > 64 || opt.rank < 0 || opt.rank >= opt.world_size) return LIFCAL_BA_ERR_INVALID_ARG;
-  if ((opt.precision != 0 && opt.precision != 1) || opt.deterministic != 0) {
-    // deterministic = 1 (ordered reductions) is declared in the ABI but does not exist yet; silently running the atomic path
-    // instead would misreport what was measured
-    g_last_error = "options.precision must be 0 or 1; options.deterministic = 1 is not implemented in this version";
+  if ((opt.precision != 0 && opt.precision != 1) || (opt.deterministic != 0 && opt.deterministic != 1)) {
+    g_last_error = "options.precision and options.deterministic must be 0 or 1";
     return LIFCAL_BA_ERR_INVALID_ARG;
   }
   lifcal_ba_handle* h = new (std::nothrow) lifcal_ba_handle();
@@ -574,6 +584,10 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   // the wave-specialised kernel wants the lanes of a pass sorted by frame, k_sweep2 (LIFCAL_SWEEP_KERNEL=2) by point
   h->use_sweep3 = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
   h->sweep_waves = sweep_waves_from_env(h->use_sweep3);
+  if (opt.deterministic == 1) {
+    if (!h->use_sweep3) { g_last_error = "options.deterministic = 1 needs k_sweep3 (unset LIFCAL_SWEEP_KERNEL)"; delete h; return LIFCAL_BA_ERR_INVALID_ARG; }
+    h->sweep_waves = 4;
+  }
   if (opt.precision == 1) {
     // fp32 residual / Jacobian evaluation exists in the wave-specialised kernel with four waves per role only
     if (!h->use_sweep3) { g_last_error = "options.precision = 1 needs k_sweep3 (unset LIFCAL_SWEEP_KERNEL)"; delete h; return LIFCAL_BA_ERR_INVALID_ARG; }
@@ -619,6 +633,12 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
     if (p->lower && p->lower[k] > -std::numeric_limits<double>::max()) h->constrained = true;
     if (p->upper && p->upper[k] < std::numeric_limits<double>::max()) h->constrained = true;
   }
+  if (opt.deterministic == 1 && (L.n_tiles != 0 || !L.special_owned.empty() || L.use_constraints || h->constrained || !L.use_points)) {
+    // ordered reductions exist on the LDS-window path only: every point must be a regular point (no distance constraints, no
+    // oversized groups, poses + points refined) and the camera block unbounded (the line search sums with atomics)
+    g_last_error = "options.deterministic = 1 supports the <2,17,6,3> arity without constraints, bounds or oversized groups (every point on the LDS-window path)";
+    return fail(LIFCAL_BA_ERR_INVALID_ARG);
+  }
 #define A(ptr, n) do { if (int rc_ = dev_alloc(h, &(ptr), (n))) return fail(rc_); } while (0)
 #define U(ptr, vec) do { if (int rc_ = dev_upload(h, &(ptr), (vec))) return fail(rc_); } while (0)
   A(d.cam, 17); A(d.cam_c, 17); A(d.views, 6 * (size_t)d.F); A(d.views_c, 6 * (size_t)d.F); A(d.pts, 3 * (size_t)d.P); A(d.pts_c, 3 * (size_t)d.P);
@@ -649,6 +669,12 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
       }
   }
   h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax, h->use_sweep3, L.pass_lanes).total * sizeof(double);
+  d.deterministic = opt.deterministic == 1 ? 1u : 0u;
+  if (d.deterministic) {
+    d.det_stride = (V2Lds(d.v2_nfmax, true, 256).off_fr + 3u + 1u) & ~1u;
+    A(d.det_slab, (size_t)std::max(1u, d.n_blocks) * d.det_stride);
+    A(d.det_slots, 4 * (size_t)std::max<uint32_t>(1024u, (std::max(d.n_owned, d.Q) + 255u) / 256u));
+  }
   if (d.n_blocks) {
 #define SET_LDS(NR, TAN, ADJ) do { if (hipFuncSetAttribute((const void*)k_sweep2<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
     if (hipFuncSetAttribute((const void*)k_sweep3<NR, TAN, ADJ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
@@ -1060,6 +1086,7 @@ int lifcal_ba_reproj_stats(lifcal_ba_handle* h, double thr, lifcal_ba_stats* out
 #define CALL_STATS(NR, TAN, ADJ) hipLaunchKernelGGL((k_stats<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)h->camc_stats, (const double*)d.ft_c, (const double*)d.lt_c, (const double*)d.pts, thr * thr, h->stats_buf, (unsigned long long*)(h->stats_buf + 4))
     DISPATCH_CFG(h, CALL_STATS);
 #undef CALL_STATS
+    if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, grid, 4u, h->stats_buf);
   }
   HIP_TRY(hipGetLastError());
   double hb[8];

@@ -24,6 +24,7 @@ constexpr uint32_t ZD_DOUBLES = 8192;   // LDS doubles reserved for the dense Z 
 
 constexpr uint32_t FRV = 27 + 6 * NCMAX;   // frame-level values a group emits: pose x pose lower (21) + pose gradient (6) + camera x pose (6 NC)
 constexpr uint32_t LDS_LIMIT_DOUBLES = 160 * 1024 / 8;
+constexpr uint32_t MISC_DOUBLES = 10;   // misc block of the LDS window: [0] cost [1] bad-U count [2] max |g_p| bits [3] two u32 counters [4..7] eight u32 hand-off counters [8..9] four u32 (deterministic emission turns)
 
 struct V2Lds {
   uint32_t nfm, nrep, np_max, zd, off_cp, off_cc, off_vec, off_fr, off_bt, off_slab, off_zd, off_misc, total;
@@ -41,14 +42,14 @@ struct V2Lds {
     off_fr = off_vec + 3 * (6 * nfm + NCMAX + 3);
     off_fr = (off_fr + 1) & ~1u;
     // replicated frame accumulators [value][rep][frame]: as many replicas (<= 8) as the 160 KiB LDS allows
-    const uint32_t fixed = off_fr + np_max * 12 + zd + 8 + 32 + 64;
+    const uint32_t fixed = off_fr + np_max * 12 + zd + MISC_DOUBLES + 32 + 64;
     uint32_t r = (LDS_LIMIT_DOUBLES - fixed) / (FRV * nfm);
     nrep = single_replica ? 1u : (r < 1 ? 1 : (r > 8 ? 8 : r));
     off_bt = off_fr + nrep * FRV * nfm;
     off_bt = (off_bt + 1) & ~1u;
-    const bool bt = single_replica && pass_lanes >= 256 && (off_bt + 16 * 256 + np_max * 12 + zd + 8 + 32 + 64 <= LDS_LIMIT_DOUBLES);
+    const bool bt = single_replica && pass_lanes >= 256 && (off_bt + 16 * 256 + np_max * 12 + zd + MISC_DOUBLES + 32 + 64 <= LDS_LIMIT_DOUBLES);
     off_slab = off_bt + (bt ? 16 * 256 : 0);
-    off_zd = off_slab + np_max * 12; off_misc = off_zd + zd; total = off_misc + 8 + 32 + 64;   // misc(8) | point ids (64 u32) | column info (<= 256 u16)
+    off_zd = off_slab + np_max * 12; off_misc = off_zd + zd; total = off_misc + MISC_DOUBLES + 32 + 64;   // misc | point ids (64 u32) | column info (<= 256 u16)
   }
   __host__ __device__ bool has_bt() const { return off_slab != off_bt; }
 };
@@ -97,8 +98,8 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
   double* slab = sm + lay.off_slab;   // per point of the pass: [0..5] U -> L^-1, [6..8] g
   double* Zd = sm + lay.off_zd;
   double* misc = sm + lay.off_misc;   // [0] cost, [1] bad-U count, [2] max |g_p| (as bits)
-  uint32_t* pidl = (uint32_t*)(misc + 8);                 // global id of each point of the pass
-  unsigned short* colinfo = (unsigned short*)(misc + 8 + 32);   // per window column: pose (lf<<8 | comp), camera 0x8000|j, rhs 0xC000
+  uint32_t* pidl = (uint32_t*)(misc + MISC_DOUBLES);                 // global id of each point of the pass
+  unsigned short* colinfo = (unsigned short*)(misc + MISC_DOUBLES + 32);   // per window column: pose (lf<<8 | comp), camera 0x8000|j, rhs 0xC000
   const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
   const uint32_t b = blockIdx.x;
   const uint32_t flo = d.blk_flo[b], nf = d.blk_nf[b];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
   // (the first pass's descriptor chain is in flight while the window is zero-filled)
   { double2* z2 = reinterpret_cast<double2*>(sm); for (uint32_t i = tid; i < lay.off_slab / 2; i += 256) z2[i] = double2{0.0, 0.0}; }
   if (tid == 0 && (lay.off_slab & 1u)) sm[lay.off_slab - 1] = 0.0;
-  if (tid < 8) misc[tid] = 0.0;
+  if (tid < MISC_DOUBLES) misc[tid] = 0.0;
   for (uint32_t cI = tid; cI < ncolp; cI += 256)
     colinfo[cI] = (cI < 6 * nf) ? (unsigned short)(((cI / 6) << 8) | (cI % 6)) : (cI < ncol - 1 ? (unsigned short)(0x8000u | (cI - 6 * nf)) : (unsigned short)0xC000u);
   double cc[NCC], gc[NC], cost = 0.0;

@@ -41,8 +41,8 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
   double* slab = sm + lay.off_slab;   // per point of the pass: [0..5] U -> L^-1, [6..8] g
   double* Zd = sm + lay.off_zd;       // dense Z matrix of the pass; during the observation loop: hand-off buffer [HV][256]
   double* misc = sm + lay.off_misc;   // [0] cost, [1] bad-U count, [2] max |g_p| (as bits)
-  uint32_t* pidl = (uint32_t*)(misc + 8);
-  unsigned short* colinfo = (unsigned short*)(misc + 8 + 32);
+  uint32_t* pidl = (uint32_t*)(misc + MISC_DOUBLES);
+  unsigned short* colinfo = (unsigned short*)(misc + MISC_DOUBLES + 32);
   // WR == 2: the four waves of a workgroup sit on the four SIMDs of the CU, one each, so a workgroup alone would put both evaluator
   // waves (300 VALU instructions per step) on SIMDs 0-1 and both accumulators (200) on SIMDs 2-3.  The second workgroup of the CU
   // (its LDS allocation does not start at 0) swaps the roles of its wave pairs, so that every SIMD hosts one evaluator and one
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
   if (ps_begin < ps_end) fetch_pass(ps_begin);
   { double2* z2 = reinterpret_cast<double2*>(sm); for (uint32_t i = tid; i < lay.off_slab / 2; i += NT) z2[i] = double2{0.0, 0.0}; }
   if (tid == 0 && (lay.off_slab & 1u)) sm[lay.off_slab - 1] = 0.0;
-  if (tid < 8) misc[tid] = 0.0;
+  if (tid < MISC_DOUBLES) misc[tid] = 0.0;
   for (uint32_t cI = tid; cI < ncolp; cI += NT)
     colinfo[cI] = (cI < 6 * nf) ? (unsigned short)(((cI / 6) << 8) | (cI % 6)) : (cI < ncol - 1 ? (unsigned short)(0x8000u | (cI - 6 * nf)) : (unsigned short)0xC000u);
 
@@ -157,6 +157,12 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
   uint32_t* hw_written = (uint32_t*)(misc + 4) + wl;       // steps the evaluator has published
   uint32_t* hw_read = (uint32_t*)(misc + 4) + 4 + wl;      // steps the accumulator has taken
   uint32_t* eval_done = (uint32_t*)(misc + 3);             // evaluator waves that have finished the emission of a pass (monotone)
+  // options.deterministic: LDS atomics of the emission are issued in WAVE ORDER (one turn counter per role, monotone over the
+  // kernel), so every LDS accumulator receives its addends in the same order on every run; inside one wave instruction the LDS
+  // unit serialises lanes that hit one address in lane order
+  const bool det = d.deterministic != 0;
+  uint32_t* turn = (uint32_t*)(misc + 8) + (role_b ? 1 : 0);
+  uint32_t my_turn = wl;                                    // + WR per pass
   // acquire / release at workgroup scope: the consumer's reads of the hand-off buffer may not be hoisted above the wait, the
   // producer's writes may not sink below the publish (on gfx950 both order LDS through lgkmcnt; no cache maintenance is involved)
   auto wait_for = [](uint32_t* flag, uint32_t need) {
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
       lds_barrier();                                                                                    // ---- barrier P2a: every accumulator has taken its last step
       if (mode == 0) zero_zd(krows);
       lds_barrier();                                                                                    // ---- barrier P2
+      if (det) wait_for(turn, my_turn);
       if (cnt > 0) {
         const double Am[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
         const double (&R)[9] = q.R; const double (&Gr)[3][3] = q.Gr;
@@ -438,6 +445,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
           }
         }
       }
+      if (det) { publish(turn, my_turn + 1); my_turn += (uint32_t)WR; }
       STAMP(6);
       // The factor phase reads only what the EVALUATOR waves emitted (U, g of the points) and runs on wave 0 (np <= 64): it
       // waits for the four evaluator waves through an LDS counter instead of a workgroup barrier, so it overlaps the longer
@@ -526,7 +534,9 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
     STAMP(9);
     if (d.robust) cost += 0.5 * c.loss_b * (log(lmant) + (double)lexp * 0.6931471805599453);
     cost = wave_sum_dpp(cost);
+    if (det) wait_for(turn, my_turn);
     if (lane == 63) atomicAdd(misc + 0, cost);
+    if (det) publish(turn, my_turn + 1);
     // the accumulator waves reduce the camera block meanwhile: same barriers
     constexpr int NVB = NCC + NC, RVB = 28;
 #pragma unroll
@@ -599,6 +609,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
       if (mode == 0) zero_zd(krows);
       lds_barrier();                                                                                    // ---- barrier P2
       STAMPB(2);
+      if (det) wait_for(turn, my_turn);
       if (mode == 0 && cnt > 0) {
         // camera x pose block of the lane's frame and the camera part of W (k_sweep2's emission, second half)
         const double (&R)[9] = q.R; const double (&Gr)[3][3] = q.Gr;
@@ -623,6 +634,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
           for (int j = 0; j < NC; ++j) atomicAdd(zrow + 6 * nf + j, R[i] * C[0][j] + R[3 + i] * C[1][j] + R[6 + i] * C[2][j]);
         }
       }
+      if (det) { publish(turn, my_turn + 1); my_turn += (uint32_t)WR; }
       STAMPB(3);
       lds_barrier();                                                                                    // ---- barrier P4 (the factor phase ran on evaluator wave 0 meanwhile)
       STAMPB(4);
@@ -719,6 +731,14 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
   }
   lds_barrier();
   STAMP(11);
+  if (det) {
+    // options.deterministic: no cross-block atomics.  The block's window (Spp | Scp | Scc | gB | hdiag | rhs) and its three
+    // scalars go to the block's slab in HBM as they are; k_det_reduce adds the slabs up in block order, one owner per entry.
+    double* out = d.det_slab + (size_t)b * d.det_stride;
+    for (uint32_t i = tid; i < lay.off_fr; i += NT) out[i] = sm[i];
+    if (tid < 3) out[lay.off_fr + tid] = misc[tid];
+    return;
+  }
   const uint32_t F6 = 6 * d.F, camrow = 3 * d.Q, camcol = F6 + 3 * d.Q;
   for (uint32_t i = tid; i < 6 * nf; i += NT) atomicAdd(d.hdiag + 6 * flo + i, vhd[i]);
   if (tid < (uint32_t)NC) atomicAdd(d.hdiag + camcol + tid, vhd[6 * NFm + tid]);

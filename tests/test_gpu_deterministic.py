@@ -1,0 +1,76 @@
+"""options.deterministic = 1: the sweep without order-dependent sums — LDS accumulation in wave order, per-block window slabs
+added up in block order by one owner per entry (k_det_reduce) instead of the cross-block f64 atomics, value kernels summed per
+workgroup in order.  Done = repeated runs, and separate handles, agree BITWISE; against the oracle the usual tolerances hold
+(its summation order is a different one)."""
+import numpy as np
+import pytest
+
+import oracle
+from lifcal_amd import BundleAdjustment, LifcalError, _capi as capi, scene
+from tests.helpers import S, problem, scaled_max_err, vec_err
+
+pytestmark = pytest.mark.gpu
+
+
+def opts(det=1, precision=0):
+    o = capi.default_options_py(); o.deterministic = det; o.precision = precision
+    return o
+
+
+CASES = [
+    ("full_robust_adj", S(6, 40, None, 0xF06, 3101, outlier_fraction=0.05)),
+    ("windowed", S(24, 120, 6, 0xF06, 3102, outlier_fraction=0.02)),
+    ("windowed_many_blocks", S(60, 2500, 8, 0x506, 3103)),
+]
+
+
+@pytest.mark.parametrize("name,spec", CASES, ids=[c[0] for c in CASES])
+def test_sweeps_are_bitwise_reproducible(built, name, spec):
+    sc = scene.make_scene(spec)
+    ref = oracle.sweep(problem(sc), radius=1e3, threads=4)
+    runs = []
+    for handle in range(2):
+        with BundleAdjustment(problem(sc), opts()) as ba:
+            for rep in range(3):
+                g = ba.sweep(1e3, want_matrices=True)
+                runs.append((g.cost, g.S.copy(), g.rhs.copy(), g.gradient_reduced.copy(), g.point_gradient.copy(), g.point_hessian_inv.copy(), g.gradient_max_norm))
+    c0 = runs[0]
+    for r in runs[1:]:
+        assert r[0] == c0[0] and r[6] == c0[6]
+        for a, b in zip(r[1:6], c0[1:6]):
+            assert np.array_equal(a, b)
+    assert abs(c0[0] - ref.cost) <= 1e-13 * ref.cost
+    assert scaled_max_err(c0[1], ref.S) < 1e-9 and vec_err(c0[2], ref.rhs) < 1e-9
+    assert vec_err(c0[4], ref.point_gradient) < 1e-10
+
+
+@pytest.mark.parametrize("precision", [0, 1])
+def test_solves_are_bitwise_reproducible(built, precision):
+    sc = scene.make_scene(scene.baseline_spec("cfg2"))
+    out = []
+    for rep in range(3):
+        pa = problem(sc)
+        with BundleAdjustment(pa, opts(1, precision)) as ba:
+            s = ba.performBundleAdjustment()
+            st = ba.calcReprojectionError()
+        out.append((pa.cam.copy(), pa.views.copy(), pa.pts.copy(), s.final_cost, s.iterations, s.final_gradient_max_norm, st.std_x, st.std_y, st.mae_x))
+    for o in out[1:]:
+        for a, b in zip(o, out[0]):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+    if precision == 0:
+        pb = problem(sc)
+        so = oracle.solve(pb, threads=oracle.hardware_threads())
+        assert (out[0][4], abs(out[0][3] - so.final_cost) <= 1e-8 * so.final_cost) == (so.iterations, True)
+        assert np.allclose(out[0][0][:9], pb.cam[:9], rtol=1e-6)
+
+
+def test_the_default_mode_is_the_atomic_one_and_unsupported_structures_are_rejected(built):
+    sc = scene.make_scene(S(6, 40, None, 0x506, 3110, n_constraints=3))
+    with pytest.raises(LifcalError, match="deterministic"):
+        BundleAdjustment(problem(sc), opts())                       # distance constraints: special points, global atomics
+    sc2 = scene.make_scene(S(6, 40, None, 0x006, 3111))
+    with pytest.raises(LifcalError, match="deterministic"):
+        BundleAdjustment(problem(sc2), opts())                      # camera-only arity runs on the global-atomic kernels
+    sc3 = scene.make_scene(S(8, 60, None, 0xF06, 3112, recalib=True))
+    with pytest.raises(LifcalError, match="deterministic"):
+        BundleAdjustment(problem(sc3), opts())                      # box bounds: the line search sums with atomics
