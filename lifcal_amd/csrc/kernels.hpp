@@ -677,7 +677,7 @@ __global__ void k_det_reduce(Dev d, int mode) {
   const uint64_t n1 = (uint64_t)F * BS, n2 = n1 + (uint64_t)NC * F6, n3 = n2 + NCC, n4 = n3 + 3ull * F6, n5 = n4 + 3ull * NC, n6 = n5 + 3;
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= n6) return;
-  const uint32_t camrow = 3 * d.Q, camcol = F6 + 3 * d.Q;
+  const uint32_t camrow = 3 * d.Q;
   // blocks whose window [flo, flo + nf) contains the frames fa <= fb: first / last candidate by first frame
   auto covering = [&](uint32_t fa, uint32_t fb, uint32_t& b0, uint32_t& b1) {
     uint32_t lo = 0, hi = nB;                       // first block with flo > fa
@@ -712,10 +712,7 @@ __global__ void k_det_reduce(Dev d, int mode) {
     dst = d.Sarrow + (size_t)(camrow + j) * d.ld + col;
   } else if (t < n3) {                              // camera x camera
     if (mode != 0) return;
-    const uint32_t q = (uint32_t)(t - n2);
-    for (uint32_t b = 0; b < nB; ++b) sum += d.det_slab[(size_t)b * d.det_stride + lay.off_cc + q];
-    uint32_t i = 0; while ((i + 1) * (i + 2) / 2 <= q) ++i;
-    dst = d.Sarrow + (size_t)(camrow + i) * d.ld + camcol + (q - i * (i + 1) / 2);
+    return;                                         // every block contributes: k_det_reduce_all (one wave per entry)
   } else if (t < n4) {                              // gB | hdiag | rhs, pose part
     const uint32_t q = (uint32_t)(t - n3), w = q / F6, col = q % F6, f = col / 6;
     if (mode != 0 && w != 1) return;
@@ -727,22 +724,41 @@ __global__ void k_det_reduce(Dev d, int mode) {
     }
     dst = (w == 0 ? d.gB : (w == 1 ? d.hdiag : d.rhsacc)) + col;
   } else if (t < n5) {                              // ... camera part
-    const uint32_t q = (uint32_t)(t - n4), w = q / NC, j = q % NC;
-    if (mode != 0 && w != 1) return;
-    for (uint32_t b = 0; b < nB; ++b) sum += d.det_slab[(size_t)b * d.det_stride + lay.off_vec + (size_t)w * vlen + 6 * NFm + j];
-    dst = (w == 0 ? d.gB : (w == 1 ? d.hdiag : d.rhsacc)) + camcol + j;
-  } else {                                          // cost, bad-U count, max |g_p|
-    if (mode != 0) return;
-    const uint32_t q = (uint32_t)(t - n5);
-    if (q < 2) { for (uint32_t b = 0; b < nB; ++b) sum += d.det_slab[(size_t)b * d.det_stride + lay.off_fr + q]; dst = d.scal + (q == 0 ? SCAL_COST : SCAL_BAD_U); }
-    else {
-      double m = 0.0;
-      for (uint32_t b = 0; b < nB; ++b) m = fmax(m, d.det_slab[(size_t)b * d.det_stride + lay.off_fr + 2]);
-      d.scal[SCAL_GMAX0 + d.rank] = fmax(d.scal[SCAL_GMAX0 + d.rank], m);
-      return;
-    }
+    return;                                         // k_det_reduce_all
+  } else {
+    return;                                         // k_det_reduce_all
   }
   *dst += sum;
+}
+
+// the entries EVERY block contributes to (camera x camera block, camera part of the three vectors, cost / bad-U count / max
+// |g_p|): one wave per entry, lane l adds the blocks l, l + 64, ... in order, the 64 partial sums are combined by a fixed
+// butterfly — a fixed association, hence bitwise reproducible, without a 255-long chain of dependent loads in one thread
+__global__ __launch_bounds__(64) void k_det_reduce_all(Dev d, int mode) {
+  const V2Lds lay(d.v2_nfmax, true, 256);
+  const uint32_t NFm = lay.nfm, vlen = 6 * NFm + NCMAX + 3, NC = d.nc, NCC = NC * (NC + 1) / 2, nB = d.n_blocks;
+  const uint32_t e = blockIdx.x, lane = threadIdx.x;
+  const uint32_t camrow = 3 * d.Q, camcol = 6 * d.F + 3 * d.Q;
+  uint32_t off; double* dst; bool is_max = false;
+  if (e < NCC) {
+    if (mode != 0) return;
+    uint32_t i = 0; while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    off = lay.off_cc + e; dst = d.Sarrow + (size_t)(camrow + i) * d.ld + camcol + (e - i * (i + 1) / 2);
+  } else if (e < NCC + 3 * NC) {
+    const uint32_t q = e - NCC, w = q / NC, j = q % NC;
+    if (mode != 0 && w != 1) return;
+    off = lay.off_vec + w * vlen + 6 * NFm + j; dst = (w == 0 ? d.gB : (w == 1 ? d.hdiag : d.rhsacc)) + camcol + j;
+  } else {
+    if (mode != 0) return;
+    const uint32_t q = e - NCC - 3 * NC;
+    off = lay.off_fr + q; is_max = q == 2;
+    dst = d.scal + (q == 0 ? SCAL_COST : (q == 1 ? SCAL_BAD_U : SCAL_GMAX0 + d.rank));
+  }
+  double v = 0.0;
+  for (uint32_t b = lane; b < nB; b += 64) { const double x = d.det_slab[(size_t)b * d.det_stride + off]; v = is_max ? fmax(v, x) : v + x; }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) { const double o = __shfl_xor(v, m, 64); v = is_max ? fmax(v, o) : v + o; }
+  if (lane == 0) { if (is_max) *dst = fmax(*dst, v); else *dst += v; }
 }
 
 // per-workgroup partial sums of the value-only kernels, added up in workgroup order (options.deterministic)

@@ -226,6 +226,7 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
       const uint32_t NCd = d.nc, F6 = 6 * d.F;
       const uint64_t n = (uint64_t)d.F * (d.bw + 1) * 36 + (uint64_t)NCd * F6 + NCd * (NCd + 1) / 2 + 3ull * F6 + 3ull * NCd + 3;
       hipLaunchKernelGGL(k_det_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d, mode);
+      hipLaunchKernelGGL(k_det_reduce_all, dim3(NCd * (NCd + 1) / 2 + 3 * NCd + 3), dim3(64), 0, h->stream, d, mode);
     }
 #undef CALL_SWEEP3
 #undef CALL_SWEEP2

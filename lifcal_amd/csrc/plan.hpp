@@ -556,9 +556,10 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     }
     const size_t rows = L.v2_tile_row0[(size_t)L.n_passes * PT];
     L.v2_u = ZeroVec<double>(); L.v2_v = ZeroVec<double>(); L.v2_lens = ZeroVec<uint32_t>();   // fresh storage: zero pages, untouched
-    L.v2_u.resize(rows * 64); L.v2_v.resize(rows * 64); L.v2_lens.resize(rows * 64); L.v2_src.assign(rows * 64, UINT32_MAX);
+    // (+ 1 row of padding: k_sweep3 requests the first two rows of a tile unconditionally, also for an empty last tile)
+    L.v2_u.resize((rows + 1) * 64); L.v2_v.resize((rows + 1) * 64); L.v2_lens.resize((rows + 1) * 64); L.v2_src.assign((rows + 1) * 64, UINT32_MAX);
     L.v2_du = ZeroVec<float>(); L.v2_dv = ZeroVec<float>();
-    if (want_f32) { L.v2_du.resize(rows * 64); L.v2_dv.resize(rows * 64); }
+    if (want_f32) { L.v2_du.resize((rows + 1) * 64); L.v2_dv.resize((rows + 1) * 64); }
     L.v2_gidx.assign((size_t)L.n_passes * PL, 0);
   clk.lap("v2: rows+alloc");
     std::vector<uint32_t> pass_block(L.n_passes, 0);

@@ -275,28 +275,43 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
       if (mode == 0 && tid < np) { fsg0 = d.sigP[3 * (size_t)fp]; fsg1 = d.sigP[3 * (size_t)fp + 1]; fsg2 = d.sigP[3 * (size_t)fp + 2]; }
       if (ps + 1 < ps_end) fetch_pass(ps + 1);
       const uint32_t krows = (3 * np + 7u) & ~7u;   // K of the product: multiple of 8 (two row groups of 4, one per role)
+      const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = (si >> 16) & 0xFFu;
+      const uint32_t fr = flo + lf;
+      // observation words of the evaluation type: (u, v) in fp64, (u - mcx, v - mcy) in fp32; lens rows of 16 ET
+      const ET* obs_u = F32 ? reinterpret_cast<const ET*>(d.v2_du) : reinterpret_cast<const ET*>(d.v2_u);
+      const ET* obs_v = F32 ? reinterpret_cast<const ET*>(d.v2_dv) : reinterpret_cast<const ET*>(d.v2_v);
+      const ET* lens_tab = F32 ? reinterpret_cast<const ET*>(d.ltf) : reinterpret_cast<const ET*>(d.lt);
+      // The pass's first dependent loads — frame row and point of the lane, the observation words of steps 0 and 1 — go out
+      // HERE, in front of the slab zero-fill and barrier P1 (an asm with a memory clobber: the compiler cannot sink them below
+      // it), so that their round trips run under the wait for the other waves instead of behind it.
+      double ftv[12], P0, P1, P2;
+      {
+        const double* ft = d.ft + (size_t)fr * FRAME_STRIDE;
+        const double* P = d.pts + 3 * (size_t)pt;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) ftv[i] = ft[i];
+        P0 = P[0]; P1 = P[1]; P2 = P[2];
+      }
+      ET ua = 0, va = 0, ub = 0, vb = 0; uint32_t lb = 0, la = 0, l0 = 0;
+      {
+        const size_t at = (size_t)row0 * 64 + lane;                                        // (row0 is a valid row even for kmax == 0: the ELL arrays are padded)
+        const size_t at2 = ((size_t)row0 + (kmax > 1 ? 1u : 0u)) * 64 + lane;
+        ua = obs_u[at]; va = obs_v[at]; l0 = d.v2_lens[at];
+        ub = obs_u[at2]; vb = obs_v[at2]; lb = d.v2_lens[at2];
+      }
       STAMP(12);
       zero_slab();
       STAMP(13);
       lds_barrier();                                                                                    // ---- barrier P1
       STAMP(0);
-      const uint32_t cnt = si & 0xFFu, lf = (si >> 8) & 0xFFu, lp = (si >> 16) & 0xFFu;
-      const uint32_t fr = flo + lf;
       typename std::conditional<F32, GroupConsts2F, GroupConsts2>::type gcn;
       {
-        const double* ft = d.ft + (size_t)fr * FRAME_STRIDE;
-        const double* P = d.pts + 3 * (size_t)pt;
-        const double P0 = P[0], P1 = P[1], P2 = P[2];
-        const double Xc = ft[0] * P0 + ft[1] * P1 + ft[2] * P2 + ft[9], Yc = ft[3] * P0 + ft[4] * P1 + ft[5] * P2 + ft[10], Zc = ft[6] * P0 + ft[7] * P1 + ft[8] * P2 + ft[11];
+        const double Xc = ftv[0] * P0 + ftv[1] * P1 + ftv[2] * P2 + ftv[9], Yc = ftv[3] * P0 + ftv[4] * P1 + ftv[5] * P2 + ftv[10], Zc = ftv[6] * P0 + ftv[7] * P1 + ftv[8] * P2 + ftv[11];
         if constexpr (F32) group_prepare2f<ADJ>(c, Xc, Yc, Zc, gcn); else group_prepare2<ADJ>(c, Xc, Yc, Zc, gcn);
       }
       double A[6] = {0, 0, 0, 0, 0, 0}, bv[3] = {0, 0, 0};
       ET* hand = reinterpret_cast<ET*>(Zd) + t256;
       constexpr uint32_t HS = LP;   // stride between the values of the hand-off buffer
-      // observation words of the evaluation type: (u, v) in fp64, (u - mcx, v - mcy) in fp32; lens rows of 16 ET
-      const ET* obs_u = F32 ? reinterpret_cast<const ET*>(d.v2_du) : reinterpret_cast<const ET*>(d.v2_u);
-      const ET* obs_v = F32 ? reinterpret_cast<const ET*>(d.v2_dv) : reinterpret_cast<const ET*>(d.v2_v);
-      const ET* lens_tab = F32 ? reinterpret_cast<const ET*>(d.ltf) : reinterpret_cast<const ET*>(d.lt);
       // two-stage prefetch: observation words (u, v, lens index) two steps ahead, the 128-byte lens row one step ahead; the
       // row's registers are free at the end of a step (the evaluation consumes the row first), so the peak does not grow.
       // All prefetch loads are UNCONDITIONAL (row index clamped; the ELL padding is valid memory): with loads under a lane
@@ -304,21 +319,13 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
       // wait for the prefetch it has just issued (HBM latency, every step).
       // The loop is unrolled by two over two sets of observation words (even / odd steps): a rotating set would make the
       // compiler copy freshly loaded registers at the back-edge, i.e. wait for the loads it has just issued.
-      ET ua = 0, va = 0, ub = 0, vb = 0; uint32_t lb = 0, la = 0;
       ET Ln[LENS_STRIDE];
       double wn0 = 0.0, wn1 = 0.0;   // F32: w of the lens in fp64 (side table), prefetched with the row
-#pragma unroll
-      for (int i = 0; i < LENS_STRIDE; ++i) Ln[i] = 0;
-      if (kmax > 0) {
-        const size_t at = (size_t)row0 * 64 + lane;
-        ua = obs_u[at]; va = obs_v[at];
-        const uint32_t l0 = d.v2_lens[at];
-        const ET* L = lens_tab + (size_t)l0 * LENS_STRIDE;
+      {
+        const ET* L = lens_tab + (size_t)l0 * LENS_STRIDE;                                   // lens 0 for idle rows: valid memory, never used
 #pragma unroll
         for (int i = 0; i < LENS_STRIDE; ++i) Ln[i] = L[i];
         if constexpr (F32) { wn0 = d.ltw[2 * (size_t)l0]; wn1 = d.ltw[2 * (size_t)l0 + 1]; }
-        const size_t at2 = ((size_t)row0 + (kmax > 1 ? 1u : 0u)) * 64 + lane;
-        ub = obs_u[at2]; vb = obs_v[at2]; lb = d.v2_lens[at2];
       }
       typename std::conditional<F32, CamF, int>::type cf{};
       if constexpr (F32) cf = cam_to_float(c);

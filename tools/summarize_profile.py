@@ -40,3 +40,19 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write
     print(f"{k[:80]:80s} fetch {fb/1e6:10.2f} MB  write {wb/1e6:10.2f} MB  total {(fb+wb)/1e6:10.2f} MB")
     traffic[short] = fb + wb
 json.dump(traffic, open(os.path.join(out, "traffic_by_kernel.json"), "w"), indent=1)
+
+# SQ issue counters of the sweep kernel (separate passes pmc_sq1 / pmc_sq2), averaged per launch
+print("\n== SQ counters per launch (k_sweep3; SQ_* cycle counters count quad-cycles) ==")
+sq = {}
+for pat in ("pmc_sq1/**/*counter_collection.csv", "pmc_sq2/**/*counter_collection.csv"):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in find(pat):
+        for r in csv.DictReader(open(f)):
+            if "k_sweep3" not in r["Kernel_Name"]:
+                continue
+            acc[r["Counter_Name"]][0] += float(r["Counter_Value"]); acc[r["Counter_Name"]][1] += 1
+    for k, v in acc.items():
+        sq[k] = v[0] / max(v[1], 1)
+for k in sorted(sq):
+    print(f"  {k:24s} {sq[k]:16.0f}")
+json.dump(sq, open(os.path.join(out, "sq_counters.json"), "w"), indent=1)
