@@ -269,6 +269,32 @@ int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size,
                    uint32_t* obs_order /* [n_obs] or NULL: sorted position -> input index, UINT32_MAX-padded */,
                    uint32_t* point_owner /* [n_points] or NULL: rank owning each point */);
 
+/* ---- shard-local problems (multi-GPU without handing every rank the whole observation list) ----
+ * lifcal_ba_create takes the WHOLE problem on every rank and keeps the observations of the points the rank owns.  For long
+ * sequences (BASELINE configs[3], configs[4]) a launcher can instead partition ONCE from the index arrays alone (pt, fr: 8 bytes
+ * per observation) with lifcal_ba_partition, hand each rank only the observations of its points, and create the rank's handle
+ * with lifcal_ba_create_shard.  The resulting layout, kernels and collectives are those of lifcal_ba_create.
+ * Host-only, no device needed for the partition.  Distance constraints are not supported on shards (they couple points across
+ * ranks: use lifcal_ba_create). */
+typedef struct lifcal_ba_partition {
+  uint32_t world_size, n_frames, n_points, band_width;   /* band_width: max over points of (last frame - first frame)          */
+  uint64_t n_obs;                                        /* observations of the whole problem                                   */
+  int32_t*  point_owner;    /* [n_points] caller-allocated: rank owning the point, -1 = not observed                            */
+  uint32_t* rank_first;     /* [world_size] caller-allocated: first frame observed by the rank's points                         */
+  uint32_t* rank_frames;    /* [world_size] caller-allocated: number of frames from rank_first to the last frame they observe   */
+  uint64_t* rank_obs;       /* [world_size] caller-allocated: observations of the rank's points                                 */
+  uint8_t*  frame_used;     /* [n_frames] caller-allocated: frame observed by any point                                         */
+} lifcal_ba_partition;
+/* fills the caller-allocated arrays of `part` (world_size must be set) from the index arrays of the whole problem: only p->n_obs,
+ * n_frames, n_points, pt and fr are read.  Same ownership rule as lifcal_ba_create (points in first-frame order, contiguous
+ * ranges balanced by observation count). */
+int lifcal_ba_partition_points(const lifcal_ba_problem* index_only, lifcal_ba_partition* part);
+/* `local` holds ONLY the observations of the points `rank` owns (any order), but the full cam / views / pts arrays (pts of other
+ * ranks' points are neither read nor written until the final gather). */
+int lifcal_ba_create_shard(const lifcal_ba_problem* local, const lifcal_ba_partition* part, const lifcal_ba_options* o, lifcal_ba_handle** out);
+/* host-only planning of a shard (what lifcal_ba_plan is for whole problems): the CPU test-suite compares the two */
+int lifcal_ba_plan_shard(const lifcal_ba_problem* local, const lifcal_ba_partition* part, int32_t rank, lifcal_ba_plan_info* info);
+
 /* ---- start values of the plenoptic parameters ----
  * Replaces reference src/CameraCalibration.cpp:456-499 (CameraCalibration::initPlenopticParameters): with
  * bL = fL z / (z - fL), z the camera-frame depth of the object point of an image point, the linear model

@@ -78,6 +78,33 @@ class WindowReport(C.Structure):   # lifcal_ba_window_report
                 ("summary", Summary)]
 
 
+class Partition(C.Structure):      # lifcal_ba_partition
+    _fields_ = [("world_size", C.c_uint32), ("n_frames", C.c_uint32), ("n_points", C.c_uint32), ("band_width", C.c_uint32), ("n_obs", C.c_uint64),
+                ("point_owner", C.POINTER(C.c_int32)), ("rank_first", uptr), ("rank_frames", uptr), ("rank_obs", C.POINTER(C.c_uint64)), ("frame_used", C.POINTER(C.c_uint8))]
+
+
+class PartitionArrays:
+    """Owns the arrays of a lifcal_ba_partition filled by lifcal_ba_partition_points."""
+
+    def __init__(self, problem: "ProblemArrays", world_size: int):
+        lib = load_library()
+        F, P = problem.struct.n_frames, problem.struct.n_points
+        self.point_owner = np.zeros(max(P, 1), np.int32); self.rank_first = np.zeros(world_size, np.uint32); self.rank_frames = np.zeros(world_size, np.uint32)
+        self.rank_obs = np.zeros(world_size, np.uint64); self.frame_used = np.zeros(max(F, 1), np.uint8)
+        self.struct = Partition(world_size, 0, 0, 0, 0, self.point_owner.ctypes.data_as(C.POINTER(C.c_int32)), as_uptr(self.rank_first), as_uptr(self.rank_frames),
+                                self.rank_obs.ctypes.data_as(C.POINTER(C.c_uint64)), self.frame_used.ctypes.data_as(C.POINTER(C.c_uint8)))
+        rc = lib.lifcal_ba_partition_points(C.byref(problem.struct), C.byref(self.struct))
+        if rc:
+            raise RuntimeError(f"lifcal_ba_partition_points: {rc}")
+
+    def shard_of(self, problem: "ProblemArrays", rank: int) -> "ProblemArrays":
+        """the rank's local problem: only the observations of the points it owns (full parameter arrays)"""
+        sel = np.flatnonzero(self.point_owner[problem.pt] == rank)
+        return ProblemArrays(problem.u[sel], problem.v[sel], problem.mcx[sel], problem.mcy[sel], problem.pt[sel], problem.fr[sel], problem.cam, problem.views, problem.pts,
+                             problem.struct.spx, problem.struct.scale, problem.struct.config, spy=problem.struct.spy, fixed_mask=problem.struct.fixed_mask,
+                             lower=problem.lower, upper=problem.upper, use_constraints=0)
+
+
 class PlanInfo(C.Structure):
     _fields_ = [("n_groups", C.c_uint32), ("n_tiles", C.c_uint32), ("n_lenses", C.c_uint32), ("n_promoted", C.c_uint32),
                 ("n_reduced", C.c_uint32), ("max_group_obs", C.c_uint32), ("n_chunks", C.c_uint32),
@@ -206,6 +233,9 @@ PROTOTYPES = {
     "lifcal_ba_last_error": (C.c_char_p, []),
     "lifcal_ba_version": (C.c_char_p, []),
     "lifcal_ba_plan": (C.c_int, [C.POINTER(Problem), C.c_int32, C.c_int32, C.POINTER(PlanInfo), uptr, uptr]),
+    "lifcal_ba_partition_points": (C.c_int, [C.POINTER(Problem), C.POINTER(Partition)]),
+    "lifcal_ba_create_shard": (C.c_int, [C.POINTER(Problem), C.POINTER(Partition), C.POINTER(Options), C.POINTER(C.c_void_p)]),
+    "lifcal_ba_plan_shard": (C.c_int, [C.POINTER(Problem), C.POINTER(Partition), C.c_int32, C.POINTER(PlanInfo)]),
 }
 
 _lib = None

@@ -46,7 +46,9 @@ def _check(lib, rc, what):
 class BundleAdjustment:
     """One bundle-adjustment problem resident on one MI355X (one rank of a point-sharded job)."""
 
-    def __init__(self, problem: capi.ProblemArrays, options: Optional[capi.Options] = None):
+    def __init__(self, problem: capi.ProblemArrays, options: Optional[capi.Options] = None, partition: Optional["capi.PartitionArrays"] = None):
+        """partition: `problem` is the rank's SHARD (only the observations of the points it owns, see capi.PartitionArrays.shard_of)
+        and the handle is made with lifcal_ba_create_shard; None: the whole problem, lifcal_ba_create."""
         self.lib = capi.load_library()
         self.problem = problem
         if options is None:
@@ -55,7 +57,11 @@ class BundleAdjustment:
         self.options = options
         self._h = C.c_void_p()
         self._hook = None
-        _check(self.lib, self.lib.lifcal_ba_create(C.byref(problem.struct), C.byref(options), C.byref(self._h)), "lifcal_ba_create")
+        self._partition = partition
+        if partition is not None:
+            _check(self.lib, self.lib.lifcal_ba_create_shard(C.byref(problem.struct), C.byref(partition.struct), C.byref(options), C.byref(self._h)), "lifcal_ba_create_shard")
+        else:
+            _check(self.lib, self.lib.lifcal_ba_create(C.byref(problem.struct), C.byref(options), C.byref(self._h)), "lifcal_ba_create")
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):

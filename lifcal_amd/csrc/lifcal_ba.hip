@@ -567,7 +567,31 @@ int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size,
   return 0;
 }
 
-int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lifcal_ba_handle** out) {
+static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, lifcal_ba_handle** out, const lifcal_ba_partition* part);
+
+int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lifcal_ba_handle** out) { return create_impl(p, o, out, nullptr); }
+
+int lifcal_ba_create_shard(const lifcal_ba_problem* local, const lifcal_ba_partition* part, const lifcal_ba_options* o, lifcal_ba_handle** out) {
+  if (!part) return LIFCAL_BA_ERR_INVALID_ARG;
+  return create_impl(local, o, out, part);
+}
+
+int lifcal_ba_partition_points(const lifcal_ba_problem* index_only, lifcal_ba_partition* part) { return partition_points(index_only, part); }
+
+int lifcal_ba_plan_shard(const lifcal_ba_problem* local, const lifcal_ba_partition* part, int32_t rank, lifcal_ba_plan_info* info) {
+  if (!part || !info) return LIFCAL_BA_ERR_INVALID_ARG;
+  Plan pl;
+  const bool frame_order = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
+  const int waves = sweep_waves_from_env(frame_order);
+  if (int rc = build_plan(local, rank, (int)part->world_size, &pl, true, waves == 2 ? 512u : 256u, UINT32_MAX, frame_order, waves == 2 ? 128u : 256u, false, part)) return rc;
+  info->n_groups = pl.n_pairs; info->n_lenses = pl.n_lenses; info->n_promoted = pl.Q;
+  info->n_reduced = pl.n_red_canon; info->max_group_obs = pl.max_group_obs; info->n_chunks = pl.n_blocks; info->max_window_frames = pl.bw + 1;
+  info->n_tiles = pl.n_tiles + pl.pass_tiles() * pl.n_passes;
+  if (getenv("LIFCAL_PLAN_HASH")) {}   // (build_plan prints the layout fingerprint itself)
+  return 0;
+}
+
+static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, lifcal_ba_handle** out, const lifcal_ba_partition* part) {
   if (!out) return LIFCAL_BA_ERR_INVALID_ARG;
   *out = nullptr;
   lifcal_ba_options opt; if (o) opt = *o; else lifcal_ba_default_options(&opt);
@@ -600,7 +624,7 @@ int lifcal_ba_create(const lifcal_ba_problem* p, const lifcal_ba_options* o, lif
   const uint32_t split_obs = getenv("LIFCAL_GROUP_SPLIT") ? (uint32_t)std::max(0, atoi(getenv("LIFCAL_GROUP_SPLIT"))) : UINT32_MAX;
   h->trace = getenv("LIFCAL_TRACE") != nullptr;
   PlanClock cclk;
-  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs, h->use_sweep3, h->sweep_waves == 2 ? 128u : 256u, opt.precision == 1);
+  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs, h->use_sweep3, h->sweep_waves == 2 ? 128u : 256u, opt.precision == 1, part);
   if (rc) { delete h; return rc; }
   cclk.lap("create: plan");
   h->prob = *p;

@@ -173,7 +173,7 @@ struct PlanClock {
 };
 
 inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl, bool enable_v2 = true, uint32_t target_blocks = 256, uint32_t split_obs = UINT32_MAX, bool frame_order = false,
-                      uint32_t pass_lanes = Plan::PASS_GROUPS, bool want_f32 = false) {
+                      uint32_t pass_lanes = Plan::PASS_GROUPS, bool want_f32 = false, const lifcal_ba_partition* part = nullptr) {
   PlanClock clk;
   if (int rc = plan_validate(p)) return rc;
   clk.lap("validate");
@@ -204,6 +204,17 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   }
   L.bw = 0;
   for (uint32_t q = 0; q < L.P; ++q) if (cnt[q]) L.bw = std::max(L.bw, last[q] - first[q]);
+  if (part) {
+    // shard-local problem (lifcal_ba_create_shard): `p` holds the observations of this rank's points only; what depends on the
+    // other ranks' observations comes from the partition computed once from the index arrays of the whole problem
+    if (part->world_size != (uint32_t)world || part->n_frames != L.F || part->n_points != L.P || !part->point_owner || !part->rank_first ||
+        !part->rank_frames || !part->frame_used || part->band_width < L.bw) return LIFCAL_BA_ERR_INVALID_ARG;
+    if ((p->config & LIFCAL_BA_CFG_REFINE_POINTS) && p->use_constraints && p->n_constraints > 0) return LIFCAL_BA_ERR_INVALID_ARG;   // constraints couple ranks
+    for (uint32_t i = 0; i < L.N; ++i) if (part->point_owner[p->pt[i]] != rank) return LIFCAL_BA_ERR_OUT_OF_RANGE;   // not this rank's observation
+    L.bw = part->band_width;
+    for (uint32_t f = 0; f < L.F; ++f) L.frame_used[f] = part->frame_used[f] ? 1 : 0;
+    for (uint32_t q = 0; q < L.P; ++q) L.point_used[q] = part->point_owner[q] >= 0 ? 1 : 0;
+  }
 
   clk.lap("per-point extents");
   // --- constraints / promotion ---
@@ -228,7 +239,9 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   std::iota(L.point_order.begin(), L.point_order.end(), 0u);
   std::stable_sort(L.point_order.begin(), L.point_order.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
   L.owner.assign(L.P, -1);
-  {
+  if (part) {
+    for (uint32_t q = 0; q < L.P; ++q) L.owner[q] = part->point_owner[q];
+  } else {
     const uint64_t total = L.N;
     uint64_t acc = 0;
     for (uint32_t r = 0; r < L.P; ++r) {
@@ -242,7 +255,9 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   }
   L.owned_points.clear();
   for (uint32_t r = 0; r < L.P; ++r) { const uint32_t q = L.point_order[r]; if (L.owner[q] == rank) L.owned_points.push_back(q); }
-  {
+  if (part) {
+    L.rk_flo.assign(part->rank_first, part->rank_first + world); L.rk_nfr.assign(part->rank_frames, part->rank_frames + world);
+  } else {
     std::vector<uint32_t> lo(world, UINT32_MAX), hi(world, 0);
     for (uint32_t q = 0; q < L.P; ++q) if (cnt[q] && L.owner[q] >= 0) { lo[L.owner[q]] = std::min(lo[L.owner[q]], first[q]); hi[L.owner[q]] = std::max(hi[L.owner[q]], last[q]); }
     L.rk_flo.assign(world, 0); L.rk_nfr.assign(world, 0);
@@ -624,6 +639,38 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     mixv(L.v2_slot); mixv(L.v2f_pt); mixv(L.v2f_fr); mixv(L.v2f_cnt); mixv(L.v2_gidx); mixv(L.v2_tile_row0); mixv(L.v2_passpt); mixv(L.tile_row0); mixv(L.pt_slot0); mixv(L.pt_nslots);
     std::fprintf(stderr, "[plan] hash %016llx\n", (unsigned long long)h);
   }
+  return 0;
+}
+
+// the ownership rule of build_plan applied to the index arrays of the whole problem (lifcal_ba_partition_points)
+inline int partition_points(const lifcal_ba_problem* p, lifcal_ba_partition* out) {
+  if (!p || !out || out->world_size < 1 || out->world_size > 64 || !out->point_owner || !out->rank_first || !out->rank_frames || !out->rank_obs || !out->frame_used) return LIFCAL_BA_ERR_INVALID_ARG;
+  if (p->n_obs && (!p->pt || !p->fr)) return LIFCAL_BA_ERR_INVALID_ARG;
+  const uint32_t P = p->n_points, F = p->n_frames, N = p->n_obs, W = out->world_size;
+  for (uint32_t i = 0; i < N; ++i) if (p->pt[i] >= P || p->fr[i] >= F) return LIFCAL_BA_ERR_OUT_OF_RANGE;
+  std::vector<uint32_t> first(P, UINT32_MAX), last(P, 0), cnt(P, 0);
+  for (uint32_t f = 0; f < F; ++f) out->frame_used[f] = 0;
+  for (uint32_t i = 0; i < N; ++i) { const uint32_t q = p->pt[i], f = p->fr[i]; first[q] = std::min(first[q], f); last[q] = std::max(last[q], f); cnt[q]++; out->frame_used[f] = 1; }
+  uint32_t bw = 0;
+  for (uint32_t q = 0; q < P; ++q) if (cnt[q]) bw = std::max(bw, last[q] - first[q]);
+  std::vector<uint32_t> order(P);
+  std::iota(order.begin(), order.end(), 0u);
+  std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return first[a] < first[b]; });
+  uint64_t acc = 0;
+  std::vector<uint32_t> lo(W, UINT32_MAX), hi(W, 0);
+  for (uint32_t r = 0; r < W; ++r) out->rank_obs[r] = 0;
+  for (uint32_t r = 0; r < P; ++r) {
+    const uint32_t q = order[r];
+    out->point_owner[q] = -1;
+    if (!cnt[q]) continue;
+    const int o = N ? (int)std::min<uint64_t>((uint64_t)W - 1, acc * (uint64_t)W / std::max<uint64_t>(N, 1)) : 0;
+    out->point_owner[q] = o;
+    acc += cnt[q];
+    out->rank_obs[o] += cnt[q];
+    lo[o] = std::min(lo[o], first[q]); hi[o] = std::max(hi[o], last[q]);
+  }
+  for (uint32_t r = 0; r < W; ++r) { out->rank_first[r] = lo[r] == UINT32_MAX ? 0 : lo[r]; out->rank_frames[r] = lo[r] == UINT32_MAX ? 0 : hi[r] - lo[r] + 1; }
+  out->n_frames = F; out->n_points = P; out->band_width = bw; out->n_obs = N;
   return 0;
 }
 

@@ -43,7 +43,14 @@ def _worker(rank, world, port, out_dir, spec_kw, mode):
         live = 5 + (sc.config & 3) + (2 if sc.config & 4 else 0)   # BASELINE configs[4]: intrinsics constant, poses + points refined
         pa = capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, sc.cam_gt.copy(), sc.views0.copy(), sc.pts0.copy(), sc.spx, sc.scale, sc.config,
                                 fixed_mask=(1 << live) - 1, use_constraints=0)
-    ba = BundleAdjustment(pa, o)
+    full = pa
+    if mode == "shard":   # the rank receives ONLY the observations of its points (lifcal_ba_partition_points + lifcal_ba_create_shard)
+        pa.struct.use_constraints = 0
+        part = capi.PartitionArrays(pa, world)
+        pa = part.shard_of(full, rank)
+        ba = BundleAdjustment(pa, o, partition=part)
+    else:
+        ba = BundleAdjustment(pa, o)
 
     def hook(ptr, count, stream):
         hip.hipStreamSynchronize(stream)
@@ -66,7 +73,7 @@ def _worker(rank, world, port, out_dir, spec_kw, mode):
         hip.hipMemcpy(recv, allb.ctypes.data, world * count * 8, 1)
         calls["gather"] += 1; calls["gather_doubles"] = count
         return 0
-    if mode in ("allgather", "windowed"):
+    if mode in ("allgather", "windowed", "shard"):
         ba.set_allgather(ghook)
     if mode == "windowed":   # lifcal_ba_solve_windowed with this handle's collectives: every window sharded over the ranks
         from lifcal_amd import performBundleAdjustmentWindowed
@@ -214,3 +221,31 @@ def test_windowed_driver_on_two_ranks(built, tmp_path):
         assert np.allclose(r["views"], pa.views, rtol=0, atol=1e-6 * (1 + np.abs(pa.views).max()))
         assert np.allclose(r["pts"], pa.pts, rtol=0, atol=1e-6 * (1 + np.abs(pa.pts).max()))
     assert np.array_equal(r0["views"], r1["views"]) and np.array_equal(r0["pts"], r1["pts"])
+
+
+def test_shard_local_problems_give_the_whole_problem_result(built, tmp_path):
+    """lifcal_ba_create_shard: every rank is handed only the observations of the points it owns (partition computed once from the
+    index arrays); sweep, solve and statistics are those of the whole-problem path and of the single-process oracle"""
+    import oracle
+    from lifcal_amd import _capi as capi, scene
+    from tests.helpers import free_port, scaled_max_err, vec_err
+    spec_kw = dict(n_frames=40, n_points=300, window=8, config=0xF06, seed=1460, outlier_fraction=0.02)
+    mp.spawn(_worker, args=(3, free_port(), str(tmp_path), spec_kw, "shard"), nprocs=3, join=True)
+    sc = scene.make_scene(scene.SceneSpec(**spec_kw))
+    ref = oracle.sweep(capi.ProblemArrays.from_scene(sc), radius=1e4, threads=4)
+    pb = capi.ProblemArrays.from_scene(sc)
+    so = oracle.solve(pb, threads=4)
+    rs = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(3)]
+    assert sum(int(r["n_local"]) for r in rs) == sc.n_obs
+    assert abs(float(rs[0]["cost0"]) - ref.cost) <= 1e-12 * ref.cost
+    assert scaled_max_err(rs[0]["S"], ref.S) < 1e-9 and vec_err(rs[0]["rhs"], ref.rhs) < 1e-9
+    for r in rs:
+        assert int(r["gather_calls"]) > 0
+        assert (int(r["it"]), int(r["term"])) == (so.iterations, so.termination)
+        assert abs(float(r["final"]) - so.final_cost) <= 1e-8 * so.final_cost
+        assert np.allclose(r["cam"][:5], pb.cam[:5], rtol=1e-6)
+        assert np.allclose(r["pts"], pb.pts, rtol=0, atol=1e-6 * (1 + np.abs(pb.pts).max()))
+        assert np.array_equal(r["pts"], rs[0]["pts"]) and np.array_equal(r["views"], rs[0]["views"])
+    stt = oracle.reproj_stats(capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, rs[0]["cam"], rs[0]["views"], rs[0]["pts"], sc.spx, sc.scale, sc.config))
+    for r in rs:
+        assert abs(float(r["stats"][0]) - stt.std_x) < 1e-9 and int(r["stats"][2]) == sc.n_obs and abs(float(r["stats"][4]) - stt.mae_x) < 1e-9
