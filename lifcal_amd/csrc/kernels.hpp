@@ -1274,3 +1274,4 @@ __global__ __launch_bounds__(256) void k_stats(Dev d, TileSet ts, const CamConst
 
 }  // namespace lifcal
 #include "bandchol.hpp"   // single-wave LDS-window band Cholesky + back-substitution
+#include "bandchol2.hpp"  // the same as segment chains: twisted (two-ended) factorisation on two workgroups

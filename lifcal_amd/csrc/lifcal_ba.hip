@@ -108,6 +108,7 @@ struct lifcal_ba_handle {
   uint8_t* frame_live_dev = nullptr;   // d.frame_live (frame is observed AND its pose is free), writable copy of the pointer
   bool trace = false;            // LIFCAL_TRACE=1: one stderr line per host decision of the LM loop, tagged with the rank
   double* Lpanel = nullptr; size_t bandw_lds = 0, backw_lds = 0; bool bandw_ok = false;
+  bool twisted = false; uint32_t tw_m = 0; double *dumpA = nullptr, *dumpB = nullptr;   // two-ended factorisation (bandchol2.hpp): frames [0, tw_m) | bw middle frames | the rest
   // profiling: 5 events per sweep (start, after tables, after k_sweep, before k_schur, after k_schur, end)
   std::vector<hipEvent_t> prof_events; uint32_t prof_cap = 0, prof_used = 0; bool prof_on = false;
   hipEvent_t prof_ev(int which) { return prof_events[(size_t)prof_used * 6 + which]; }
@@ -294,7 +295,17 @@ int read_sweep_scalars(lifcal_ba_handle* h, double* cost, double* gmax, double* 
 
 int launch_linear_solve(lifcal_ba_handle* h) {
   Dev& d = h->d;
-  if (h->bandw_ok) {   // window and solution vector fit LDS: one wave walks the chain
+  if (h->bandw_ok && h->twisted) {
+    // twisted factorisation: the chain from both ends on two workgroups, the bw middle frames + arrow last; back-substitution inside out
+    const uint32_t m = h->tw_m, bw = d.bw, n2 = d.F - m - bw;
+    const BandSeg sa{+1, 0u, m + bw, m, 0u, h->dumpA}, sb{-1, d.F - 1, n2 + bw, n2, 0u, h->dumpB}, sm{+1, m, bw, bw, 1u, nullptr};
+    hipLaunchKernelGGL(k_band_chol_seg, dim3(2), dim3(256), h->bandw_lds, h->stream, d, h->Lpanel, sa, sb);
+    const uint32_t nmerge = bw * (bw + 1) / 2 * 36 + (d.NA + 1) * bw * 6 + (d.NA + 1) * (d.NA + 1);
+    hipLaunchKernelGGL(k_band_merge, dim3((nmerge + 255) / 256), dim3(256), 0, h->stream, d, m, bw, (const double*)h->dumpA, (const double*)h->dumpB);
+    hipLaunchKernelGGL(k_band_chol_seg, dim3(1), dim3(256), h->bandw_lds, h->stream, d, h->Lpanel, sm, sm);
+    hipLaunchKernelGGL(k_band_backsolve_seg, dim3(1), dim3(64), h->backw_lds, h->stream, d, (const double*)h->Lpanel, sm, sm);
+    hipLaunchKernelGGL(k_band_backsolve_seg, dim3(2), dim3(64), h->backw_lds, h->stream, d, (const double*)h->Lpanel, sa, sb);
+  } else if (h->bandw_ok) {   // window and solution vector fit LDS: one wave walks the chain
     hipLaunchKernelGGL(k_band_chol_w, dim3(1), dim3(256), h->bandw_lds, h->stream, d, h->Lpanel);
     hipLaunchKernelGGL(k_band_backsolve_w, dim3(1), dim3(64), h->backw_lds, h->stream, d, (const double*)h->Lpanel);
   } else {
@@ -764,6 +775,15 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
       A(h->Lpanel, (size_t)std::max(1u, d.F) * (6 * (size_t)d.bw + d.NA + 1) * 6);
       if (hipFuncSetAttribute((const void*)k_band_chol_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bandw_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
       if (hipFuncSetAttribute((const void*)k_band_backsolve_w, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->backw_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
+      // long enough for two chains to pay: eliminate from both ends (LIFCAL_TWISTED=0: the single chain)
+      h->twisted = d.use_poses && d.bw >= 1 && d.F >= 3 * d.bw + 8 && !(getenv("LIFCAL_TWISTED") && atoi(getenv("LIFCAL_TWISTED")) == 0);
+      if (h->twisted) {
+        h->tw_m = (d.F - d.bw) / 2;
+        const size_t nd = (size_t)d.bw * (d.bw + 1) / 2 * 36 + (size_t)(d.NA + 1) * d.bw * 6 + (size_t)(d.NA + 1) * (d.NA + 1);
+        A(h->dumpA, nd); A(h->dumpB, nd);
+        if (hipFuncSetAttribute((const void*)k_band_chol_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bandw_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
+        if (hipFuncSetAttribute((const void*)k_band_backsolve_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->backw_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
+      }
     }
   }
 #undef A

@@ -135,3 +135,31 @@ def test_huge_group_is_not_truncated(built):
     with BundleAdjustment(mk()) as ba:
         got = ba.sweep(1e4, want_matrices=True)
     assert abs(got.cost - ref.cost) <= 1e-12 * ref.cost and scaled_max_err(got.S, ref.S) < 1e-9
+
+
+@pytest.mark.parametrize("spec", [S(24, 120, 6, 0xF06, 6101, outlier_fraction=0.02), S(60, 400, 8, 0x506, 6102), S(41, 300, 10, 0xF06, 6103, recalib=True, outlier_fraction=0.02),
+                                  S(23, 100, 6, 0xF06, 6104)],
+                         ids=["w6_f24", "w8_f60", "w10_f41_recalib", "w6_f23_single_chain_limit"])
+def test_twisted_band_factorisation_equals_the_single_chain(built, monkeypatch, spec):
+    """bandchol2.hpp: eliminating the pose chain from both ends on two workgroups (+ the middle frames and the arrow last) solves the
+    same reduced system as the single chain of bandchol.hpp: same LM trajectory, same result (to the round-off of a different
+    elimination order), and both follow the oracle"""
+    import oracle
+    sc = scene.make_scene(spec)
+    res = {}
+    for tw in ("1", "0"):
+        monkeypatch.setenv("LIFCAL_TWISTED", tw)
+        pa = problem(sc)
+        with BundleAdjustment(pa) as ba:
+            s = ba.performBundleAdjustment()
+        res[tw] = (pa, s)
+    (p1, s1), (p0, s0) = res["1"], res["0"]
+    assert (s1.iterations, s1.successful_steps, s1.unsuccessful_steps, s1.termination) == (s0.iterations, s0.successful_steps, s0.unsuccessful_steps, s0.termination)
+    assert abs(s1.final_cost - s0.final_cost) <= 1e-11 * s0.final_cost
+    # (poses and points move along the weakly damped gauge directions: round-off of the two elimination orders shows there first)
+    assert np.allclose(p1.cam, p0.cam, rtol=1e-8, atol=1e-13)
+    assert np.allclose(p1.views, p0.views, rtol=0, atol=1e-6 * (1 + np.abs(p0.views).max())) and np.allclose(p1.pts, p0.pts, rtol=0, atol=1e-6 * (1 + np.abs(p0.pts).max()))
+    pb = problem(sc)
+    so = oracle.solve(pb, threads=4)
+    assert (s1.iterations, s1.termination) == (so.iterations, so.termination)
+    assert abs(s1.final_cost - so.final_cost) <= 1e-8 * so.final_cost
