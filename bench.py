@@ -78,19 +78,25 @@ def cpu_baseline(sc, pa, budget_s=25.0):
 
     def arm(analytic, budget):
         oracle.sweep(pa, radius=1e4, threads=threads, want_matrices=False, analytic=analytic)   # warm-up (page faults, thread start)
-        best, reps, t_end = None, 0, time.time() + budget
+        best_jac, best_schur, best_total, reps, t_end = None, None, None, 0, time.time() + budget
         while reps < 2 or (time.time() < t_end and reps < 10):
             r = oracle.sweep(pa, radius=1e4, threads=threads, want_matrices=False, analytic=analytic)
-            if best is None or r.seconds < best.seconds:
-                best = r
+            best_jac = r.seconds_eval if best_jac is None else min(best_jac, r.seconds_eval)
+            best_schur = r.seconds_schur if best_schur is None else min(best_schur, r.seconds_schur)
+            best_total = r.seconds if best_total is None else min(best_total, r.seconds)
             reps += 1
-        return {"value": sc.n_obs / best.seconds, "unit": "obs/s", "seconds": best.seconds, "seconds_jacobian": best.seconds_eval,
-                "seconds_schur": best.seconds_schur, "best_of": reps}
+        return {"seconds": best_total, "seconds_jacobian": best_jac, "seconds_schur": best_schur, "best_of": reps}
     dual = arm(False, 0.5 * budget_s)
     ana = arm(True, 0.3 * budget_s)
+    # the two arms differ in the Jacobian evaluation only; the dense Schur elimination behind it is the same code (and, on 256
+    # threads, a noisy one): each arm is priced with its own best Jacobian time + the best elimination time seen in either arm
+    schur = min(dual["seconds_schur"], ana["seconds_schur"])
+    for a in (dual, ana):
+        a["value"] = sc.n_obs / (a["seconds_jacobian"] + schur); a["unit"] = "obs/s"
     out = {"value": dual["value"], "unit": "obs/s", "cores": threads, "cpu_model": cpu_model(), "kind": "port",
            "sample": f"the whole bench workload, identical flattened input: {sc.spec.n_frames} frames, {sc.spec.n_points} points, {sc.n_obs} obs, "
-                     f"config {sc.config:#x}; one Jacobian + dense-Schur sweep, dual-number (autodiff-equivalent) Jacobian, best of {dual['best_of']}",
+                     f"config {sc.config:#x}; one Jacobian + dense-Schur sweep, dual-number (autodiff-equivalent) Jacobian, best of {dual['best_of']} "
+                     f"(best Jacobian time + best elimination time)",
            "arms": {"dual_number": dual, "analytic": ana}}
     try:   # secondary: the same CPU restatement through a full solve of a smaller BASELINE config (works on a private copy)
         sc3 = scene.make_scene(scene.baseline_spec("cfg3"))

@@ -320,6 +320,9 @@ typedef struct lifcal_init_result {
   int32_t reserved;
 } lifcal_init_result;
 int lifcal_init_plenoptic(const lifcal_init_problem* p, int32_t device, lifcal_init_result* out);
+/* Replaces reference src/CameraCalibration.cpp:503-512 (CameraCalibration::initPlenopticParametersRecalibration): recalib mode takes fL
+ * and B from the previous calibration (calibData->getFixedParameters) and starts bL0 at fL - 2 B.  Host arithmetic, no device. */
+int lifcal_init_plenoptic_recalibration(double fL_fixed, double B_fixed, lifcal_init_result* out);
 
 #ifdef __cplusplus
 }

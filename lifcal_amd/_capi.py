@@ -229,6 +229,7 @@ PROTOTYPES = {
     "lifcal_ba_get_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
     "lifcal_ba_destroy": (None, [C.c_void_p]),
     "lifcal_init_plenoptic": (C.c_int, [C.POINTER(InitProblem), C.c_int32, C.POINTER(InitResult)]),
+    "lifcal_init_plenoptic_recalibration": (C.c_int, [C.c_double, C.c_double, C.POINTER(InitResult)]),
     "lifcal_ba_strerror": (C.c_char_p, [C.c_int]),
     "lifcal_ba_last_error": (C.c_char_p, []),
     "lifcal_ba_version": (C.c_char_p, []),

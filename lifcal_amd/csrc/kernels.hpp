@@ -984,18 +984,22 @@ __global__ void k_update_reduced(Dev d, double* partial) {
 }
 
 // points: delta_P = -U^-1 (g_p + W_p delta_B) for eliminated points, reduced solution for promoted ones
+// FOUR lanes per point (a quad): the ~10 groups of a regular point are dealt round the quad and the three partial sums meet
+// with two quad shuffles — one thread per point walked its groups serially on a third of the chip (45 -> 15 us at the metric point)
 __global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by the host side */) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t tq = blockIdx.x * blockDim.x + threadIdx.x;   // thread index: promoted points below
+  const uint32_t t = tq >> 2, sub = threadIdx.x & 3u;
   double gtd = 0.0, ddd = 0.0, st2 = 0.0, x2 = 0.0;
   if (t < d.n_owned) {
     const uint32_t p = d.owned[t];
     if (d.promoted[p] < 0) {
       const double* acc = d.ptacc + (size_t)p * 36;
-      double v[3] = {acc[6], acc[7], acc[8]};
+      double v[3] = {0.0, 0.0, 0.0};
+      if (sub == 0) { v[0] = acc[6]; v[1] = acc[7]; v[2] = acc[8]; }
       const uint32_t ns = d.pt_nslots[p];
       const uint32_t ncon = d.pt_cons0 ? d.pt_cons0[p + 1] - d.pt_cons0[p] : 0;
       if (d.pt_special[p]) {
-        for (uint32_t bi = 0; bi < 1 + ns + ncon; ++bi) {
+        if (sub == 0) for (uint32_t bi = 0; bi < 1 + ns + ncon; ++bi) {
           const WBlock B = point_block(d, p, bi, ns);
           for (uint32_t j = 0; j < B.width; ++j) {
             const double dl = d.delta_red[B.base + j];
@@ -1005,11 +1009,11 @@ __global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by th
       } else {
         // regular point (LDS-window kernel): the sweep stored only A per lane; W_pose delta_f = R^T A (Gr delta_a + delta_t)
         // with Gr = d(R P)/d(angles) rebuilt from the frame table and the point (k_sweep2's emission, same formulas)
-        { const WBlock B = point_block(d, p, 0, ns);
+        if (sub == 0) { const WBlock B = point_block(d, p, 0, ns);
           for (uint32_t j = 0; j < B.width; ++j) { const double dl = d.delta_red[B.base + j]; v[0] += B.W[j] * dl; v[1] += B.W[B.ldw + j] * dl; v[2] += B.W[2 * B.ldw + j] * dl; } }
         const double P0 = d.pts[3 * (size_t)p], P1 = d.pts[3 * (size_t)p + 1], P2 = d.pts[3 * (size_t)p + 2];
         const uint32_t s0 = d.pt_slot0[p];
-        for (uint32_t k = 0; k < ns; ++k) {
+        for (uint32_t k = sub; k < ns; k += 4) {
           const uint32_t sidx = s0 + k, f = d.gid_fr[sidx];
           const double* ft = d.ft + (size_t)f * FRAME_STRIDE;
           const double* A = d.Av + (size_t)sidx * 6;
@@ -1029,8 +1033,11 @@ __global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by th
           v[0] += R[0] * u0 + R[3] * u1 + R[6] * u2; v[1] += R[1] * u0 + R[4] * u1 + R[7] * u2; v[2] += R[2] * u0 + R[5] * u1 + R[8] * u2;
         }
       }
+      // the quad's partial sums (fixed order: the same bits on every run); the four lanes of a quad took the same branches above
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { v[k] += __shfl_xor(v[k], 1, 64); v[k] += __shfl_xor(v[k], 2, 64); }
       const double* iv = d.Uinv + 9 * (size_t)p;
-      for (int k = 0; k < 3; ++k) {
+      if (sub == 0) for (int k = 0; k < 3; ++k) {
         const double dl = -(iv[3 * k] * v[0] + iv[3 * k + 1] * v[1] + iv[3 * k + 2] * v[2]);
         const double xo = d.pts[3 * (size_t)p + k];
         d.pts_c[3 * (size_t)p + k] = xo + dl;
@@ -1040,11 +1047,11 @@ __global__ void k_backsub(Dev d, double* partial /* 4 doubles, all-reduced by th
     }
   }
   // promoted points are replicated: every rank applies the same reduced step; rank 0 accounts for the norms
-  if (t < d.Q) {
+  if (tq < d.Q) {
     const uint32_t F6 = 6 * d.F;
-    const uint32_t pid = d.promoted_ids[t];
+    const uint32_t pid = d.promoted_ids[tq];
     for (int k = 0; k < 3; ++k) {
-      const double dl = d.delta_red[F6 + 3 * t + k];
+      const double dl = d.delta_red[F6 + 3 * tq + k];
       const double xo = d.pts[3 * (size_t)pid + k];
       d.pts_c[3 * (size_t)pid + k] = xo + dl;
       if (d.rank == 0) { st2 += dl * dl; x2 += xo * xo; }

@@ -320,7 +320,7 @@ int launch_linear_solve(lifcal_ba_handle* h) {
 int launch_candidate(lifcal_ba_handle* h) {
   Dev& d = h->d;
   hipLaunchKernelGGL(k_update_reduced, dim3(1), dim3(256), 0, h->stream, d, h->partial);
-  const uint32_t n = std::max(d.n_owned, d.Q);
+  const uint32_t n = std::max(4 * d.n_owned, d.Q);   // four lanes per owned point
   if (d.use_points && n) {
     hipLaunchKernelGGL(k_backsub, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, h->partial);
     if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, (n + 255) / 256, 4u, h->partial);
@@ -561,6 +561,13 @@ static int sweep_waves_from_env(bool sweep3) {
   return w == 2 ? 2 : 4;
 }
 
+int lifcal_init_plenoptic_recalibration(double fL_fixed, double B_fixed, lifcal_init_result* out) {
+  if (!out) return LIFCAL_BA_ERR_INVALID_ARG;
+  out->B_init = B_fixed; out->bL0_init = fL_fixed - 2 * B_fixed;   // reference :509
+  out->n_used = 0; out->rank = 2; out->reserved = 0;
+  return 0;
+}
+
 int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size, lifcal_ba_plan_info* info,
                    uint32_t* obs_order, uint32_t* point_owner) {
   Plan pl;
@@ -709,7 +716,7 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
   if (d.deterministic) {
     d.det_stride = (V2Lds(d.v2_nfmax, true, 256).off_fr + 3u + 1u) & ~1u;
     A(d.det_slab, (size_t)std::max(1u, d.n_blocks) * d.det_stride);
-    A(d.det_slots, 4 * (size_t)std::max<uint32_t>(1024u, (std::max(d.n_owned, d.Q) + 255u) / 256u));
+    A(d.det_slots, 4 * (size_t)std::max<uint32_t>(1024u, (std::max(4 * d.n_owned, d.Q) + 255u) / 256u));
   }
   if (d.n_blocks) {
 #define SET_LDS(NR, TAN, ADJ) do { if (hipFuncSetAttribute((const void*)k_sweep2<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \

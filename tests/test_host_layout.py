@@ -40,6 +40,15 @@ def test_library_exports_every_declared_symbol(built):
     assert b"gfx950" in lib.lifcal_ba_version()
 
 
+def test_recalibration_start_values(built):
+    """reference src/CameraCalibration.cpp:503-512: bL0_init = fL_init - 2 B_init from the previous calibration's fL and B"""
+    lib = capi.load_library()
+    r = capi.InitResult()
+    assert lib.lifcal_init_plenoptic_recalibration(35.0, 0.4, C.byref(r)) == 0
+    assert r.B_init == 0.4 and r.bL0_init == 35.0 - 2 * 0.4
+    assert lib.lifcal_init_plenoptic_recalibration(35.0, 0.4, None) == -1
+
+
 def test_default_options_match_reference_settings(built):
     lib = capi.load_library()
     o = capi.Options(); lib.lifcal_ba_default_options(C.byref(o))
