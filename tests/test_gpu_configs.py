@@ -100,3 +100,30 @@ def test_cfg5_recalibration_arms(built):
     pa2 = capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, sc.cam_gt.copy(), sc.views0.copy(), sc.pts0.copy(),
                              sc.spx, sc.scale, sc.config, fixed_mask=(1 << live) - 1)
     check_solve(pa2, fixed=tuple(range(live)))
+
+
+def test_cfg5_streaming_as_baseline_words_it(built):
+    """BASELINE configs[4] in its own words: "recalib mode, intrinsics fixed, 2000-frame streaming pose+point refine, fp32 residuals / fp64
+    normal-eq accumulate" — the frame-windowed driver (windows of 250 frames advancing by 200) with options.precision = 1, every intrinsic
+    constant at its calibrated value.  One window is resident at a time; the result must be a solution of the WHOLE problem at the noise
+    level, close to what the all-at-once solve of the same problem reaches."""
+    from lifcal_amd import performBundleAdjustmentWindowed
+    sc = scene.make_scene(scene.baseline_spec("cfg5"))
+    live = 5 + (sc.config & 3) + (2 if sc.config & 4 else 0)
+    mk = lambda: capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, sc.cam_gt.copy(), sc.views0.copy(), sc.pts0.copy(), sc.spx, sc.scale, sc.config,
+                                    fixed_mask=(1 << live) - 1, use_constraints=0)
+    o = capi.default_options_py(); o.precision = 1
+    pw = mk()
+    reps = performBundleAdjustmentWindowed(pw, 250, 50, options=o)
+    assert [r.first_frame for r in reps] == list(range(0, 2000, 200)) and reps[-1].first_frame + reps[-1].n_frames == 2000
+    assert all(r.summary.termination in (1, 2) for r in reps) and all(r.n_fixed_frames == 50 for r in reps[1:]) and reps[0].n_fixed_frames == 0
+    assert max(r.n_obs for r in reps) < 0.2 * sc.n_obs                                   # a window is a fraction of the problem
+    assert np.array_equal(pw.cam, sc.cam_gt)
+    with BundleAdjustment(pw) as ba:
+        st_win = ba.calcReprojectionError()
+    pf = mk()
+    with BundleAdjustment(pf, o) as ba:
+        ba.performBundleAdjustment()
+        st_full = ba.calcReprojectionError()
+    assert st_win.num_points == sc.n_obs and st_win.std_x < 1.1 * st_full.std_x and st_win.std_y < 1.1 * st_full.std_y
+    assert st_win.std_x < 0.6 and st_win.num_inliers > 0.95 * sc.n_obs                   # 0.1 px noise + 2 % outliers at +-5 px
