@@ -73,6 +73,7 @@ struct Dev {
   // options.deterministic = 1: per-block slabs of the LDS windows (k_det_reduce sums them in block order), per-workgroup slots
   // of the value-only kernels (k_det_sum)
   uint32_t deterministic, det_stride;
+  uint32_t schur_mfma;           // 1: the Schur product of k_sweep3 runs on the fp64 matrix pipe (LIFCAL_SCHUR_MFMA)
   double *det_slab, *det_slots;
   const uint32_t* special_owned;
   // constraints

@@ -30,6 +30,9 @@ using namespace lifcal;
 #ifndef LIFCAL_DEFAULT_SWEEP_WAVES
 #define LIFCAL_DEFAULT_SWEEP_WAVES 4
 #endif
+#ifndef LIFCAL_DEFAULT_SCHUR_MFMA
+#define LIFCAL_DEFAULT_SCHUR_MFMA 0
+#endif
 
 namespace {
 
@@ -712,6 +715,7 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
       }
   }
   h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax, h->use_sweep3, L.pass_lanes).total * sizeof(double);
+  d.schur_mfma = (getenv("LIFCAL_SCHUR_MFMA") ? atoi(getenv("LIFCAL_SCHUR_MFMA")) : LIFCAL_DEFAULT_SCHUR_MFMA) ? 1u : 0u;
   d.deterministic = opt.deterministic == 1 ? 1u : 0u;
   if (d.deterministic) {
     d.det_stride = (V2Lds(d.v2_nfmax, true, 256).off_fr + 3u + 1u) & ~1u;
