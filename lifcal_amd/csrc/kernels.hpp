@@ -73,7 +73,6 @@ struct Dev {
   // options.deterministic = 1: per-block slabs of the LDS windows (k_det_reduce sums them in block order), per-workgroup slots
   // of the value-only kernels (k_det_sum)
   uint32_t deterministic, det_stride;
-  uint32_t schur_mfma;           // 1: the Schur product of k_sweep3 runs on the fp64 matrix pipe (LIFCAL_SCHUR_MFMA)
   double *det_slab, *det_slots;
   const uint32_t* special_owned;
   // constraints
@@ -1283,3 +1282,4 @@ __global__ __launch_bounds__(256) void k_stats(Dev d, TileSet ts, const CamConst
 }  // namespace lifcal
 #include "bandchol.hpp"   // single-wave LDS-window band Cholesky + back-substitution
 #include "bandchol2.hpp"  // the same as segment chains: twisted (two-ended) factorisation on two workgroups
+#include "bandchol3.hpp"  // block odd-even reduction over many workgroups (long sequences)

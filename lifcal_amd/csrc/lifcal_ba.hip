@@ -30,9 +30,6 @@ using namespace lifcal;
 #ifndef LIFCAL_DEFAULT_SWEEP_WAVES
 #define LIFCAL_DEFAULT_SWEEP_WAVES 4
 #endif
-#ifndef LIFCAL_DEFAULT_SCHUR_MFMA
-#define LIFCAL_DEFAULT_SCHUR_MFMA 0
-#endif
 
 namespace {
 
@@ -111,6 +108,7 @@ struct lifcal_ba_handle {
   uint8_t* frame_live_dev = nullptr;   // d.frame_live (frame is observed AND its pose is free), writable copy of the pointer
   bool trace = false;            // LIFCAL_TRACE=1: one stderr line per host decision of the LM loop, tagged with the rank
   double* Lpanel = nullptr; size_t bandw_lds = 0, backw_lds = 0; bool bandw_ok = false;
+  CrPlan cr; bool use_cr = false;   // block odd-even reduction (bandchol3.hpp): long sequences
   bool twisted = false; uint32_t tw_m = 0; double *dumpA = nullptr, *dumpB = nullptr;   // two-ended factorisation (bandchol2.hpp): frames [0, tw_m) | bw middle frames | the rest
   // profiling: 5 events per sweep (start, after tables, after k_sweep, before k_schur, after k_schur, end)
   std::vector<hipEvent_t> prof_events; uint32_t prof_cap = 0, prof_used = 0; bool prof_on = false;
@@ -298,7 +296,10 @@ int read_sweep_scalars(lifcal_ba_handle* h, double* cost, double* gmax, double* 
 
 int launch_linear_solve(lifcal_ba_handle* h) {
   Dev& d = h->d;
-  if (h->bandw_ok && h->twisted) {
+  if (h->use_cr) {
+    const CrSys sys{d.Sband, d.Sarrow, d.delta_red, d.step + ST_CHOL_FAIL, d.F, d.bw, d.NA, d.ld};
+    cr_solve_launch(h->cr, sys, h->stream);
+  } else if (h->bandw_ok && h->twisted) {
     // twisted factorisation: the chain from both ends on two workgroups, the bw middle frames + arrow last; back-substitution inside out
     const uint32_t m = h->tw_m, bw = d.bw, n2 = d.F - m - bw;
     const BandSeg sa{+1, 0u, m + bw, m, 0u, h->dumpA}, sb{-1, d.F - 1, n2 + bw, n2, 0u, h->dumpB}, sm{+1, m, bw, bw, 1u, nullptr};
@@ -715,7 +716,6 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
       }
   }
   h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax, h->use_sweep3, L.pass_lanes).total * sizeof(double);
-  d.schur_mfma = (getenv("LIFCAL_SCHUR_MFMA") ? atoi(getenv("LIFCAL_SCHUR_MFMA")) : LIFCAL_DEFAULT_SCHUR_MFMA) ? 1u : 0u;
   d.deterministic = opt.deterministic == 1 ? 1u : 0u;
   if (d.deterministic) {
     d.det_stride = (V2Lds(d.v2_nfmax, true, 256).off_fr + 3u + 1u) & ~1u;
@@ -795,6 +795,17 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
         if (hipFuncSetAttribute((const void*)k_band_chol_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->bandw_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
         if (hipFuncSetAttribute((const void*)k_band_backsolve_seg, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->backw_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
       }
+    }
+  }
+  {
+    // block odd-even reduction of the band + arrow system: log2(F / bw) levels on up to F / (2 bw) workgroups instead of a chain of
+    // F / 2 steps on two; pays from ~32 super-blocks on (LIFCAL_CR=1 / 0 forces / forbids it where it is applicable)
+    const char* ev = getenv("LIFCAL_CR");
+    const int want = ev ? atoi(ev) : -1;
+    if (d.use_poses && want != 0 && cr_eligible(d.F, d.bw, d.NA) && (want == 1 || cr_geometry(d.F, d.bw, d.NA).nb >= 32) && cr_plan(h->cr, d.F, d.bw, d.NA)) {
+      A(h->cr.ws.P, cr_ws_doubles_P(h->cr.ws)); A(h->cr.ws.D, cr_ws_doubles_D(h->cr.ws)); A(h->cr.ws.A, cr_ws_doubles_A(h->cr.ws));
+      A(h->cr.ws.U, cr_ws_doubles_U(h->cr.ws)); A(h->cr.ws.x, cr_ws_doubles_x(h->cr.ws));
+      h->use_cr = true;
     }
   }
 #undef A

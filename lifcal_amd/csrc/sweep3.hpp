@@ -221,61 +221,33 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
         for (int q = 0; q < 4; ++q) cur[r][q] = nxt[r][q];
     }
   };
-  // one entry (ci >= cj) of Z^T Z into the window
-  auto emit_entry = [&](uint32_t ci, uint32_t cj, double dv) {
-    if (ci >= ncol || cj >= ncol || ci < cj) return;
-    const uint32_t ii = colinfo[ci], jj = colinfo[cj];
-    if (!(ii & 0x8000u)) {            // pose x pose
-      const uint32_t lfi = ii >> 8, lfj = jj >> 8;
-      Spp[(size_t)(lfi * (lfi + 1) / 2 + lfj) * 36 + (ii & 0xFFu) * 6 + (jj & 0xFFu)] -= dv;
-    } else if (!(ii & 0x4000u)) {     // camera row
-      const uint32_t jc = ii & 0xFFu;
-      if (!(jj & 0x8000u)) Scp[(size_t)jc * 6 * NFm + cj] -= dv;
-      else Scc[jc * (jc + 1) / 2 + (jj & 0xFFu)] -= dv;
-    } else if (cj < ncol - 1) {       // rhs row: W^T U^-1 g
-      if (!(jj & 0x8000u)) vrhs[cj] += dv; else vrhs[6 * NFm + (jj & 0xFFu)] += dv;
-    }
-  };
   auto emit_tile = [&](uint32_t mi, uint32_t mj, const double (&acc16)[4][4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      const uint32_t ci = 4 * mi + i;
+      const uint32_t ii = colinfo[ci < ncolp ? ci : 0];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) emit_entry(4 * mi + i, 4 * mj + j, acc16[i][j]);
-  };
-  // ---- the same product on the fp64 matrix pipe (d.schur_mfma; round 2: at two waves per SIMD v_mfma_f64_16x16x4_f64 delivers
-  // 1.4x the vector rate and needs a quarter of the LDS reads of the 4x4 register tiles).  16x16 output tiles over the lower
-  // triangle, tile tt -> wave tt % 8, up to four tiles per wave kept across the passes: evaluator waves in the registers of
-  // their 4x4 tile, accumulator waves in `bt`.  Operands straight from Zd: A[i][k] = Z[k0 + k][16 ti + i] (lane = i + 16 k),
-  // B[k][j] = Z[k0 + k][16 tj + j]; result D[row = (lane >> 4) + 4 r][col = lane & 15] (the f64 map, not the f32 one).
-  const uint32_t nt16 = (ncol + 15u) >> 4, ntri16 = nt16 * (nt16 + 1) / 2;
-  auto mfma_tiles = [&](uint32_t krows, double (&acc16)[4][4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t tt = w + 8u * (uint32_t)q;
-      if (tt >= ntri16) continue;
-      uint32_t ti, tj; tri_decode(tt, ti, tj);
-      const double* za = Zd + (size_t)(lane >> 4) * zs + 16 * ti + (lane & 15u);
-      const double* zb = Zd + (size_t)(lane >> 4) * zs + 16 * tj + (lane & 15u);
-      v4f64 acc = {acc16[q][0], acc16[q][1], acc16[q][2], acc16[q][3]};
-#pragma unroll 4
-      for (uint32_t k0 = 0; k0 < krows; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(za[(size_t)k0 * zs], zb[(size_t)k0 * zs], acc, 0, 0, 0);
-      acc16[q][0] = acc[0]; acc16[q][1] = acc[1]; acc16[q][2] = acc[2]; acc16[q][3] = acc[3];
-    }
-  };
-  auto mfma_emit = [&](const double (&acc16)[4][4]) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const uint32_t tt = w + 8u * (uint32_t)q;
-      if (tt >= ntri16) continue;
-      uint32_t ti, tj; tri_decode(tt, ti, tj);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) emit_entry(16 * ti + (lane >> 4) + 4u * (uint32_t)r, 16 * tj + (lane & 15u), acc16[q][r]);
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t cj = 4 * mj + j;
+        const double dv = acc16[i][j];
+        if (ci >= ncol || cj >= ncol || ci < cj) continue;
+        const uint32_t jj = colinfo[cj];
+        if (!(ii & 0x8000u)) {            // pose x pose
+          const uint32_t lfi = ii >> 8, lfj = jj >> 8;
+          Spp[(size_t)(lfi * (lfi + 1) / 2 + lfj) * 36 + (ii & 0xFFu) * 6 + (jj & 0xFFu)] -= dv;
+        } else if (!(ii & 0x4000u)) {     // camera row
+          const uint32_t jc = ii & 0xFFu;
+          if (!(jj & 0x8000u)) Scp[(size_t)jc * 6 * NFm + cj] -= dv;
+          else Scc[jc * (jc + 1) / 2 + (jj & 0xFFu)] -= dv;
+        } else if (cj < ncol - 1) {       // rhs row: W^T U^-1 g
+          if (!(jj & 0x8000u)) vrhs[cj] += dv; else vrhs[6 * NFm + (jj & 0xFFu)] += dv;
+        }
+      }
     }
   };
   // WR == 2: 128 threads per role cannot own the ~230 tiles of a 12-frame window one each; all 256 threads share the tiles of
   // every pass (fresh accumulators per pass, Spp -= tile at its end)
-  const bool use_mfma = (WR == 4) && (mode == 0) && d.schur_mfma != 0 && lay.has_bt() && ntri16 <= 32 && ncolp + 2 <= zs;
-  const bool keep_tiles = !use_mfma && (WR == 4) && (mode == 0) && ntri <= LP;
+  const bool keep_tiles = (WR == 4) && (mode == 0) && ntri <= LP;
   const bool ksplit = keep_tiles && lay.has_bt();
   const bool share_tiles = (WR != 4) && (mode == 0);
   double* bt = sm + lay.off_bt;   // [16][256] partial tiles of the accumulator threads
@@ -538,9 +510,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
         z_phase(np);
         lds_barrier();                                                                                  // ---- barrier P5
         STAMP(3);
-        if (use_mfma) {
-          mfma_tiles(krows, tacc);
-        } else if (keep_tiles) {
+        if (keep_tiles) {
           if (tid < ntri) gemm_tile(mi0, mj0, 0, ksplit ? 8u : 4u, krows, tacc);
         } else {
           for (uint32_t t = tid; t < ntri; t += (share_tiles ? NT : LP)) {
@@ -559,7 +529,6 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
       STAMP(4);
     }
     STAMP(8);
-    if (use_mfma) mfma_emit(tacc);
     if (keep_tiles && tid < ntri) {
       if (ksplit) {   // the accumulator thread's partial tile (complete: barrier P6 of the last pass)
 #pragma unroll
@@ -680,18 +649,6 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
         z_phase(np);
         lds_barrier();                                                                                  // ---- barrier P5
       }
-      if (use_mfma) {   // this wave's 16x16 tiles of the Schur product; their accumulators live in LDS between passes
-        double acc16[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc16[i][j] = bt[(i * 4 + j) * LP + t256];
-        mfma_tiles(krows, acc16);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j) bt[(i * 4 + j) * LP + t256] = acc16[i][j];
-      }
       if (ksplit && t256 < ntri) {   // rows 4-7 of every 8 of the Schur product; the partial tile lives in LDS between passes
         uint32_t mi, mj; tri_decode(t256, mi, mj);
         double acc16[4][4];
@@ -719,14 +676,6 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
       }
       lds_barrier();                                                                                    // ---- barrier P6
       STAMPB(5);
-    }
-    if (use_mfma) {   // the accumulator waves' tiles go into the window (every entry of the window has one owner: no race with the evaluators' tiles)
-      double acc16[4][4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc16[i][j] = bt[(i * 4 + j) * LP + t256];
-      mfma_emit(acc16);
     }
     {  // sign/scale folding for the thread's camera x camera block and camera gradient
       int t = 0;

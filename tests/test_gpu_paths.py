@@ -163,3 +163,30 @@ def test_twisted_band_factorisation_equals_the_single_chain(built, monkeypatch, 
     so = oracle.solve(pb, threads=4)
     assert (s1.iterations, s1.termination) == (so.iterations, so.termination)
     assert abs(s1.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+
+
+@pytest.mark.parametrize("spec", [S(24, 120, 6, 0xF06, 6201, outlier_fraction=0.02), S(60, 400, 8, 0x506, 6202), S(41, 300, 10, 0xF06, 6203, recalib=True, outlier_fraction=0.02),
+                                  S(97, 500, 4, 0xF06, 6204), S(50, 150, 3, 0x706, 6205)],
+                         ids=["w6_f24", "w8_f60", "w10_f41_recalib", "w4_f97", "w3_f50"])
+def test_block_odd_even_reduction_equals_the_chain(built, monkeypatch, spec):
+    """bandchol3.hpp: the block odd-even reduction of the band + arrow system (log2(F / bw) levels, one workgroup per eliminated
+    super-block) solves the same reduced system as the chain factorisations: same LM trajectory, same result to the round-off of
+    another elimination order, and both follow the oracle"""
+    import oracle
+    sc = scene.make_scene(spec)
+    res = {}
+    for cr in ("1", "0"):
+        monkeypatch.setenv("LIFCAL_CR", cr)
+        pa = problem(sc)
+        with BundleAdjustment(pa) as ba:
+            s = ba.performBundleAdjustment()
+        res[cr] = (pa, s)
+    (p1, s1), (p0, s0) = res["1"], res["0"]
+    assert (s1.iterations, s1.successful_steps, s1.unsuccessful_steps, s1.termination) == (s0.iterations, s0.successful_steps, s0.unsuccessful_steps, s0.termination)
+    assert abs(s1.final_cost - s0.final_cost) <= 1e-11 * s0.final_cost
+    assert np.allclose(p1.cam, p0.cam, rtol=1e-8, atol=1e-13)
+    assert np.allclose(p1.views, p0.views, rtol=0, atol=1e-6 * (1 + np.abs(p0.views).max())) and np.allclose(p1.pts, p0.pts, rtol=0, atol=1e-6 * (1 + np.abs(p0.pts).max()))
+    pb = problem(sc)
+    so = oracle.solve(pb, threads=4)
+    assert (s1.iterations, s1.termination) == (so.iterations, so.termination)
+    assert abs(s1.final_cost - so.final_cost) <= 1e-8 * so.final_cost
