@@ -17,7 +17,7 @@
 //                  four waves); only the pivot column travels through LDS, double-buffered: one barrier per column.  The step
 //                  code is fully unrolled over the column index with static register indices and NO guards (the diagonal block
 //                  is padded with identity columns to 4 NQ): ~60 instructions per column instead of ~450 with run-time guards.
-//   k_cr_products  per KEPT block b one workgroup: D_b -= P_r(b-s) P_r(b-s)^T + P_l(b+s) P_l(b+s)^T and the same for its arrow
+//   k_cr_products  (fp64 MFMA) per KEPT block b one workgroup: D_b -= P_r(b-s) P_r(b-s)^T + P_l(b+s) P_l(b+s)^T and the same for its arrow
 //                  rows (every kept block has ONE writer and a fixed summation order: the factorisation is bitwise
 //                  reproducible — all ranks of a multi-GPU run factor the same replicated system and must agree); per
 //                  ELIMINATED block e one workgroup: the coupling of its neighbours U_rl = P_r P_l^T (+ transpose) and its share
@@ -81,14 +81,12 @@ inline size_t cr_factor_lds(uint32_t nrows, int NQ) {
   const uint32_t nrg = cr_threads(nrows) / 4;
   return ((size_t)nrows * (4 * NQ + 1) + 2 + 2 * (4 * (size_t)nrg + 4 * (size_t)NQ) + 8) * sizeof(double);
 }
-inline size_t cr_products_lds(const CrWs& w) {
-  const uint32_t mp = (w.m + 3u) & ~3u, ldx = mp + 2, ldxa = ((w.nax + 3u) & ~3u) + 2;
-  const size_t kept = (size_t)2 * w.m * (ldx + ldxa) + (size_t)256 * 16 + (size_t)128 * 16;
-  const size_t elim = (size_t)w.m * (2 * ldx + ldxa);
-  return std::max(kept, elim) * sizeof(double);
+inline size_t cr_products_lds(const CrWs& w) {   // k-major operand copies, row strides 80 (<= 64 rows) and 48 (<= 32 rows) doubles
+  const size_t mk = (w.m + 3u) & ~3u;
+  return std::max((size_t)2 * w.m * (80 + 48), mk * (2 * 80 + 48)) * sizeof(double);
 }
 inline bool cr_eligible(uint32_t F, uint32_t bw, uint32_t NA) {
-  if (bw < 1 || NA > 31 || 6 * bw > 64) return false;
+  if (bw < 1 || NA > 31 || NA < 1 || 6 * bw > 64) return false;
   const CrWs w = cr_geometry(F, bw, NA);
   const int nq = cr_factor_nq(w.m);
   if (w.nb < 4 || nq == 0) return false;
@@ -135,6 +133,8 @@ LIFCAL_DEV CrSrc cr_src_S(const CrSys& s, uint32_t fi, uint32_t a, uint32_t fj, 
 // through a 64 KB instruction cache, 81 us for 72 columns); cp in uniform branches around every block (the compiler moves the
 // blocks out of line and spills the column values: 2.4 KB of scratch per lane); a rolled loop over the quads with the registers
 // shifted down after every quad and a fall-through switch over the live quads (AGPR traffic: 97 us per panel).
+// (Measured and dropped: deferring the updates nobody waits for behind the next barrier, so that they run under the next
+// column's LDS reads — same time, 36 more registers: the step is bound by instruction issue of the single wave per SIMD.)
 template <int NQ>
 LIFCAL_DEV bool cr_panel_factor(double (&x)[4][NQ], uint32_t rg, uint32_t cp, uint32_t NRG, double* cb) {
   constexpr uint32_t NC = 4 * NQ;
@@ -336,256 +336,206 @@ __global__ __launch_bounds__(TPB) void k_cr_factor(CrSys s, CrWs w, uint32_t lev
   }
 #ifdef CR_STAMPS
   CRSTAMP(4);
-  if (tid == 0) for (int i = 0; i < 5; ++i) ((unsigned long long*)w.x)[(size_t)w.nb * m + nax + 8 * (level * 64 + blockIdx.x) + i] = cst[i];
+  if (tid == 0) for (int i = 0; i < 5; ++i) ((unsigned long long*)w.x)[(size_t)w.nb * m + nax + nax * nax + 8 * (level * 64 + blockIdx.x) + i] = cst[i];
 #endif
 }
 
-// k-major LDS copies of up to four row-major row blocks (m columns each, stride m) in ONE batch of loads: block q has n[q] rows at
-// G[q] (null: skipped, the zeros stay) and goes to L[q][(koff[q] + k) * ld[q] + r].  One wave per row, the rows of all blocks dealt
-// round-robin to the waves, RBS rows per wave in flight.
-template <int RBS>
-LIFCAL_DEV void cr_stage_all(const double* G0, const double* G1, const double* G2, const double* G3, double* L0, double* L1, double* L2, double* L3,
-                             uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3, uint32_t ld01, uint32_t ld23, uint32_t ko1, uint32_t ko3,
-                             uint32_t m, uint32_t tid, uint32_t T) {   // blocks 0 / 2 go to k offset 0, blocks 1 / 3 to ko1 / ko3
-  const uint32_t wv = tid >> 6, ln = tid & 63u, nwv = T >> 6;
-  const uint32_t n01 = n0 + n1, n012 = n01 + n2, ntot = n012 + n3;
-  const double* valid = G0 ? G0 : (G1 ? G1 : G2);
-  for (uint32_t k0 = 0; k0 < m; k0 += 64) {
-    const uint32_t k = k0 + ln;
-    const bool kok = k < m;
-    for (uint32_t rb = wv; rb < ntot; rb += RBS * nwv) {
-      double v[RBS];
-#pragma unroll
-      for (int u = 0; u < RBS; ++u) {
-        const uint32_t vr = rb + (uint32_t)u * nwv;      // wave-uniform: the selects below are scalar
-        const bool q0 = vr < n0, q1 = !q0 && vr < n01, q2 = !q0 && !q1 && vr < n012;
-        const double* G = q0 ? G0 : q1 ? G1 : q2 ? G2 : G3;
-        const uint32_t r = vr - (q0 ? 0u : q1 ? n0 : q2 ? n01 : n012);
-        const bool ok = vr < ntot && G != nullptr && kok;
-        v[u] = *(ok ? G + (size_t)r * m + k : valid);
-      }
-#pragma unroll
-      for (int u = 0; u < RBS; ++u) {
-        const uint32_t vr = rb + (uint32_t)u * nwv;
-        const bool q0 = vr < n0, q1 = !q0 && vr < n01, q2 = !q0 && !q1 && vr < n012;
-        const double* G = q0 ? G0 : q1 ? G1 : q2 ? G2 : G3;
-        double* L = q0 ? L0 : q1 ? L1 : q2 ? L2 : L3;
-        const uint32_t r = vr - (q0 ? 0u : q1 ? n0 : q2 ? n01 : n012);
-        const uint32_t ldq = (q0 || q1) ? ld01 : ld23, ko = q0 ? 0u : q1 ? ko1 : q2 ? 0u : ko3;
-        if (vr < ntot && G != nullptr && kok) L[(size_t)(ko + k) * ldq + r] = v[u];
-      }
-    }
-  }
+// ---- products on the fp64 matrix pipe ----
+// X Y^T in 16x16 tiles with v_mfma_f64_16x16x4_f64 from k-major LDS copies of the operands (Ls[k * ld + row]): per MFMA a lane
+// reads ONE double of each operand for 16 multiply-adds of its own — a quarter of the LDS traffic of 4x4 register tiles, which
+// had made the first version of this kernel LDS-bound (12 waves x 54 k-steps x 4 KB: 20 k cycles of the CU's LDS pipe).
+// Operand map (as in the Schur product experiment of sweep3.hpp): A[i][k] = X[k0 + k][16 ti + i] in lane i + 16 k,
+// B[k][j] = Y[k0 + k][16 tj + j] in lane j + 16 k, result entry (16 ti + 4 r + (lane >> 4), 16 tj + (lane & 15)) in acc[r].
+// Row strides ld = 16 (mod 32) doubles: the four k-rows of an operand fetch fall on disjoint LDS banks per half-wave.
+typedef double cr_v4f64 __attribute__((ext_vector_type(4)));
+constexpr uint32_t CR_LDY = 80, CR_LDA = 48;   // operands of <= 64 rows (m <= 64) and <= 32 rows (nax <= 32)
+LIFCAL_DEV cr_v4f64 cr_mfma_tile(const double* Xs, uint32_t ldx, const double* Ys, uint32_t ldy, uint32_t ti, uint32_t tj, uint32_t K, cr_v4f64 acc, uint32_t lane) {
+  const double* xa = Xs + (size_t)(lane >> 4) * ldx + 16 * ti + (lane & 15u);
+  const double* yb = Ys + (size_t)(lane >> 4) * ldy + 16 * tj + (lane & 15u);
+  for (uint32_t k0 = 0; k0 < K; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[(size_t)k0 * ldx], yb[(size_t)k0 * ldy], acc, 0, 0, 0);
+  return acc;
 }
-// 4x4 tile (ti, tj) of X Y^T over k in [k0, k1) from k-major copies
-LIFCAL_DEV void cr_tile(const double* Xs, uint32_t ldx, const double* Ys, uint32_t ldy, uint32_t ti, uint32_t tj, uint32_t k0, uint32_t k1, double (&acc)[4][4]) {
-  const double* xa = Xs + 4 * ti; const double* yb = Ys + 4 * tj;
-#pragma unroll 2
-  for (uint32_t k = k0; k < k1; ++k) {
-    const double2 a0 = *reinterpret_cast<const double2*>(xa + (size_t)k * ldx), a1 = *reinterpret_cast<const double2*>(xa + (size_t)k * ldx + 2);
-    const double2 b0 = *reinterpret_cast<const double2*>(yb + (size_t)k * ldy), b1 = *reinterpret_cast<const double2*>(yb + (size_t)k * ldy + 2);
-    const double av[4] = {a0.x, a0.y, a1.x, a1.y}, bv[4] = {b0.x, b0.y, b1.x, b1.y};
+// rows wv, wv + nwv, ... of a row-major block G (n rows x m columns, stride m; null: nothing) into Ls[(koff + k) * ldl + r]; lanes = k
+// (m <= 64).  The loads of ALL blocks of a kernel are issued before the first store (CR_STAGE_LOAD ... CR_STAGE_STORE).
+template <int NU>
+LIFCAL_DEV void cr_stage_load(const double* G, uint32_t n, uint32_t m, uint32_t wv, uint32_t nwv, uint32_t ln, const double* valid, double (&v)[NU]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int u = 0; u < NU; ++u) { const uint32_t r = wv + (uint32_t)u * nwv; v[u] = *((G && r < n && ln < m) ? G + (size_t)r * m + ln : valid); }
+}
+template <int NU>
+LIFCAL_DEV void cr_stage_store(const double* G, uint32_t n, uint32_t m, uint32_t wv, uint32_t nwv, uint32_t ln, double* Ls, uint32_t ldl, uint32_t koff, const double (&v)[NU]) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
-  }
+  for (int u = 0; u < NU; ++u) { const uint32_t r = wv + (uint32_t)u * nwv; if (G && r < n && ln < m) Ls[(size_t)(koff + ln) * ldl + r] = v[u]; }
 }
 
-// blockIdx < nk: kept block b = 2 i s: D_b and A_b lose what its eliminated neighbours eL = b - s and eR = b + s take away
-// (threads 0-511: the tiles of D, K split in the eL half and the eR half; threads 512-767: the tiles of A, likewise);
-// otherwise eliminated block e: U_rl (+ transpose) and U_aa.
+// blockIdx < nk: kept block b = 2 i s: D_b and A_b lose what its eliminated neighbours eL = b - s and eR = b + s take away: one
+// accumulation chain per output tile over K = 2 m (eL's share first, then eR's: a fixed order); otherwise eliminated block e:
+// U_rl (+ transpose) and U_aa.  12 waves, output tiles dealt round-robin.
 __global__ __launch_bounds__(768) void k_cr_products(CrSys s, CrWs w, uint32_t level) {
   extern __shared__ __attribute__((aligned(16))) double crl[];
   const uint32_t tid = threadIdx.x, T = CR_PROD_THREADS, m = w.m, nax = w.nax, st = 1u << level;
+  const uint32_t wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63u, nwv = T >> 6;
   const bool last = level >= w.levels;   // block 0 as the last "eliminated" block: only its share of the arrow block
   const uint32_t nk = last ? 0u : (cr_n_active(w.nb, level) + 1) / 2;
-  const uint32_t mp = (m + 3u) & ~3u, nt = mp / 4, ldx = mp + 2, nta = (nax + 3u) / 4, ldxa = 4 * nta + 2;
+  const uint32_t mt = (m + 15u) / 16, nat = (nax + 15u) / 16, mk = (m + 3u) & ~3u;
+  constexpr int NUM = 6, NUA = 3;   // rows per wave of an m-row / nax-row block: 12 waves x 6 >= 64, 12 x 3 >= 32
   if (blockIdx.x < nk) {
     const uint32_t b = (2 * blockIdx.x) << level;
     const bool hasL = b >= st, hasR = b + st < w.nb;
     const double* PL = hasL ? w.P + (size_t)(b - st) * w.prow * m : nullptr;   // panel of eL: its P_r rows are b's variables
     const double* PR = hasR ? w.P + (size_t)(b + st) * w.prow * m : nullptr;   // panel of eR: its P_l rows are b's variables
-    double* Ys = crl;                         // [2m][ldx]: P_r(eL) | P_l(eR), k-major
-    double* Xa = Ys + (size_t)2 * m * ldx;    // [2m][ldxa]: P_a(eL) | P_a(eR)
-    double* red = Xa + (size_t)2 * m * ldxa;  // partial tiles of the second K halves
-    double* reda = red + 256 * 16;
-#ifdef CR_STAMPS
-    unsigned long long pst[8];
-#define PSTAMP(i) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pst[i]) :: "memory")
-#else
-#define PSTAMP(i) do { } while (0)
-#endif
-    PSTAMP(0);
-    const uint32_t grp = tid >> 8, t = tid & 255u;
-    uint32_t ti = 0, tj = 0; bool mine = false, is_a = false, second = false;
-    if (grp < 2) { mine = t < nt * nt; ti = t / nt; tj = t - ti * nt; second = grp == 1; }
-    else { is_a = true; const uint32_t q = t & 127u; mine = q < nta * nt; ti = q / nt; tj = q - ti * nt; second = (t >> 7) == 1; }
-    // the block's own values first: their loads run under the staging
-    double own[4][4];
+    const double* valid = PL ? PL : PR;
+    double* Ys = crl;                              // [2m][CR_LDY]: P_r(eL) | P_l(eR), k-major
+    double* Xa = Ys + (size_t)2 * m * CR_LDY;      // [2m][CR_LDA]: P_a(eL) | P_a(eR)
+    double v0[NUM], v1[NUM], v2[NUA], v3[NUA];
+    cr_stage_load<NUM>(PL ? PL + (size_t)m * m : nullptr, m, m, wv, nwv, ln, valid, v0);
+    cr_stage_load<NUM>(PR, m, m, wv, nwv, ln, valid, v1);
+    cr_stage_load<NUA>(PL ? PL + 2 * (size_t)m * m : nullptr, nax, m, wv, nwv, ln, valid, v2);
+    cr_stage_load<NUA>(PR ? PR + 2 * (size_t)m * m : nullptr, nax, m, wv, nwv, ln, valid, v3);
+    // the block's own values: tile task q = wv + 12 t; D tiles first (mt x mt), then the A tiles (nat x mt)
+    const uint32_t ntask = mt * mt + nat * mt;
+    cr_v4f64 own[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t q = wv + 12u * t;
+      if (q >= ntask) continue;
+      const bool is_a = q >= mt * mt;
+      const uint32_t qq = is_a ? q - mt * mt : q, ti = qq / mt, tj = qq - ti * mt, c = 16 * tj + (ln & 15u);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) own[i][j] = 0.0;
-    if (mine && !second) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t r = 4 * ti + i, c = 4 * tj + j;
-          if (c >= m) continue;
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const uint32_t r = 16 * ti + 4 * r4 + (ln >> 4);
+        double o = 0.0;
+        if (c < m && r < (is_a ? nax : m)) {
           if (!is_a) {
-            if (r >= m) continue;
-            if (level == 0) { const CrSrc q = cr_src_S(s, b * s.bw + r / 6, r % 6, b * s.bw + c / 6, c % 6); own[i][j] = *q.p * q.mul + q.add; }
-            else own[i][j] = w.D[(size_t)b * m * m + r * m + c];
+            if (level == 0) { const CrSrc sq = cr_src_S(s, b * s.bw + r / 6, r % 6, b * s.bw + c / 6, c % 6); o = *sq.p * sq.mul + sq.add; }
+            else o = w.D[(size_t)b * m * m + r * m + c];
           } else {
-            if (r >= nax) continue;
-            if (level == 0) { const uint32_t f = b * s.bw + c / 6; own[i][j] = f < s.F ? s.Sarrow[(size_t)r * s.ld + 6 * f + c % 6] : 0.0; }
-            else own[i][j] = w.A[(size_t)b * nax * m + r * m + c];
+            if (level == 0) { const uint32_t f = b * s.bw + c / 6; o = f < s.F ? s.Sarrow[(size_t)r * s.ld + 6 * f + c % 6] : 0.0; }
+            else o = w.A[(size_t)b * nax * m + r * m + c];
           }
         }
+        own[t][r4] = o;
+      }
     }
-    PSTAMP(1);
-    for (uint32_t i = tid; i < 2 * m * (ldx + ldxa); i += T) crl[i] = 0.0;
+    for (uint32_t i = tid; i < 2 * m * (CR_LDY + CR_LDA); i += T) crl[i] = 0.0;
     __syncthreads();
-    PSTAMP(2);
-    cr_stage_all<16>(PL ? PL + (size_t)m * m : nullptr, PR, PL ? PL + 2 * (size_t)m * m : nullptr, PR ? PR + 2 * (size_t)m * m : nullptr,
-                     Ys, Ys, Xa, Xa, m, m, nax, nax, ldx, ldxa, m, m, m, tid, T);   // P_r(eL) | P_l(eR) ; P_a(eL) | P_a(eR)
+    cr_stage_store<NUM>(PL ? PL + (size_t)m * m : nullptr, m, m, wv, nwv, ln, Ys, CR_LDY, 0, v0);
+    cr_stage_store<NUM>(PR, m, m, wv, nwv, ln, Ys, CR_LDY, m, v1);
+    cr_stage_store<NUA>(PL ? PL + 2 * (size_t)m * m : nullptr, nax, m, wv, nwv, ln, Xa, CR_LDA, 0, v2);
+    cr_stage_store<NUA>(PR ? PR + 2 * (size_t)m * m : nullptr, nax, m, wv, nwv, ln, Xa, CR_LDA, m, v3);
     __syncthreads();
-    PSTAMP(3);
-    double acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int t = 0; t < 2; ++t) {
+      const uint32_t q = wv + 12u * t;
+      if (q >= ntask) continue;   // wave-uniform
+      const bool is_a = q >= mt * mt;
+      const uint32_t qq = is_a ? q - mt * mt : q, ti = qq / mt, tj = qq - ti * mt, c = 16 * tj + (ln & 15u);
+      cr_v4f64 acc = {0, 0, 0, 0};
+      acc = cr_mfma_tile(is_a ? Xa : Ys, is_a ? CR_LDA : CR_LDY, Ys, CR_LDY, ti, tj, 2 * m, acc, ln);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-    if (mine) cr_tile(is_a ? Xa : Ys, is_a ? ldxa : ldx, Ys, ldx, ti, tj, second ? m : 0, second ? 2 * m : m, acc);
-    double* rd = is_a ? reda + (size_t)(t & 127u) * 16 : red + (size_t)t * 16;
-    if (mine && second) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) rd[i * 4 + j] = acc[i][j];
-    }
-    PSTAMP(4);
-    __syncthreads();
-    PSTAMP(5);
-    if (mine && !second) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t r = 4 * ti + i, c = 4 * tj + j;
-          if (c >= m || r >= (is_a ? nax : m)) continue;
-          const double v = (own[i][j] - acc[i][j]) - rd[i * 4 + j];   // eL's share first, then eR's: a fixed order
-          if (!is_a) w.D[(size_t)b * m * m + r * m + c] = v; else w.A[(size_t)b * nax * m + r * m + c] = v;
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const uint32_t r = 16 * ti + 4 * r4 + (ln >> 4);
+        if (c < m && r < (is_a ? nax : m)) {
+          const double vv = own[t][r4] - acc[r4];
+          if (!is_a) w.D[(size_t)b * m * m + r * m + c] = vv; else w.A[(size_t)b * nax * m + r * m + c] = vv;
         }
+      }
     }
-#ifdef CR_STAMPS
-    PSTAMP(6);
-    if (tid == 0 && blockIdx.x == 1) for (int i = 0; i < 7; ++i) ((unsigned long long*)w.x)[(size_t)w.nb * m + nax + 8 * (level * 64 + 32) + i] = pst[i];
-#endif
     return;
   }
   const uint32_t e = last ? 0u : (2 * (blockIdx.x - nk) + 1) << level;
   const bool has_r = !last && e + st < w.nb;
   const double* P = w.P + (size_t)e * w.prow * m;
-  double* Xs = crl; double* Ys = Xs + (size_t)m * ldx; double* Za = Ys + (size_t)m * ldx;   // P_r | P_l | P_a, k-major
-  for (uint32_t i = tid; i < m * (2 * ldx + ldxa); i += T) crl[i] = 0.0;
+  // the last launch also adds up the arrow products of the blocks 1..nb-1 (coalesced: a thread per entry, the blocks dealt to
+  // G thread groups, each group in ascending block order, the groups combined in group order: reproducible) for k_cr_arrow
+  const uint32_t naa = nax * nax, G = last ? (T / naa > 4 ? 4u : T / naa) : 0u;
+  double part_aa = 0.0;
+  if (last && G > 0 && tid < G * naa) {
+    const uint32_t g = tid / naa, ent = tid - g * naa;
+    for (uint32_t e0 = 1 + g; e0 < w.nb; e0 += 16 * G) {
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const uint32_t ee = e0 + (uint32_t)u * G; v[u] = w.U[(size_t)(ee < w.nb ? ee : 1u) * w.ustride + w.off_aa() + ent]; }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) { const uint32_t ee = e0 + (uint32_t)u * G; if (ee < w.nb) part_aa += v[u]; }
+    }
+  }
+  double* Xs = crl; double* Ys = Xs + (size_t)mk * CR_LDY; double* Za = Ys + (size_t)mk * CR_LDY;   // P_r | P_l | P_a, k-major, K padded to a multiple of 4
+  double v0[NUM], v1[NUM], v2[NUA];
+  cr_stage_load<NUM>(has_r ? P + (size_t)m * m : nullptr, m, m, wv, nwv, ln, P, v0);
+  cr_stage_load<NUM>(P, m, m, wv, nwv, ln, P, v1);
+  cr_stage_load<NUA>(P + 2 * (size_t)m * m, nax, m, wv, nwv, ln, P, v2);
+  for (uint32_t i = tid; i < mk * (2 * CR_LDY + CR_LDA); i += T) crl[i] = 0.0;
   __syncthreads();
-  cr_stage_all<16>(has_r ? P + (size_t)m * m : nullptr, P, P + 2 * (size_t)m * m, nullptr, Xs, Ys, Za, Za, m, m, nax, 0, ldx, ldxa, 0, 0, m, tid, T);
+  cr_stage_store<NUM>(has_r ? P + (size_t)m * m : nullptr, m, m, wv, nwv, ln, Xs, CR_LDY, 0, v0);
+  cr_stage_store<NUM>(P, m, m, wv, nwv, ln, Ys, CR_LDY, 0, v1);
+  cr_stage_store<NUA>(P + 2 * (size_t)m * m, nax, m, wv, nwv, ln, Za, CR_LDA, 0, v2);
   __syncthreads();
   double* U = w.U + (size_t)e * w.ustride;
-  double acc[4][4];
+  const uint32_t nrl = has_r ? mt * mt : 0u, ntask = nrl + nat * nat;
+  for (uint32_t q = wv; q < ntask; q += nwv) {
+    const bool is_aa = q >= nrl;
+    const uint32_t qq = is_aa ? q - nrl : q, tw = is_aa ? nat : mt, ti = qq / tw, tj = qq - ti * tw, c = 16 * tj + (ln & 15u);
+    cr_v4f64 acc = {0, 0, 0, 0};
+    acc = cr_mfma_tile(is_aa ? Za : Xs, is_aa ? CR_LDA : CR_LDY, is_aa ? Za : Ys, is_aa ? CR_LDA : CR_LDY, ti, tj, mk, acc, ln);
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-  if (tid < nt * nt) {
-    if (has_r) {
-      const uint32_t ti = tid / nt, tj = tid - ti * nt;
-      cr_tile(Xs, ldx, Ys, ldx, ti, tj, 0, m, acc);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t r = 4 * ti + i, c = 4 * tj + j;
-          if (r < m && c < m) { U[w.off_rl() + r * m + c] = acc[i][j]; U[w.off_lr() + c * m + r] = acc[i][j]; }
-        }
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const uint32_t r = 16 * ti + 4 * r4 + (ln >> 4);
+      if (is_aa) { if (r < nax && c < nax) U[w.off_aa() + r * nax + c] = acc[r4]; }
+      else if (r < m && c < m) { U[w.off_rl() + r * m + c] = acc[r4]; U[w.off_lr() + c * m + r] = acc[r4]; }
     }
-  } else if (tid >= 512 && tid - 512 < nta * nta) {
-    const uint32_t q = tid - 512, ti = q / nta, tj = q - ti * nta;
-    cr_tile(Za, ldxa, Za, ldxa, ti, tj, 0, m, acc);
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t r = 4 * ti + i, c = 4 * tj + j;
-        if (r < nax && c < nax) U[w.off_aa() + r * nax + c] = acc[i][j];
-      }
+  }
+  if (last) {
+    __syncthreads();
+    double* part = crl;   // [G][naa]
+    if (G > 0 && tid < G * naa) part[tid] = part_aa;
+    __syncthreads();
+    if (tid < naa) {
+      double sacc = 0.0;
+      if (G > 0) { for (uint32_t g = 0; g < G; ++g) sacc += part[g * naa + tid]; }
+      else { for (uint32_t ee = 1; ee < w.nb; ++ee) sacc += w.U[(size_t)ee * w.ustride + w.off_aa() + tid]; }
+      w.x[(size_t)w.nb * m + nax + tid] = sacc;
+    }
+    for (uint32_t t2 = tid + T; t2 < naa; t2 += T) {   // (nax^2 <= 1024 > 768 threads: the entries beyond the first pass)
+      double sacc = 0.0;
+      for (uint32_t ee = 1; ee < w.nb; ++ee) sacc += w.U[(size_t)ee * w.ustride + w.off_aa() + t2];
+      w.x[(size_t)w.nb * m + nax + t2] = sacc;
+    }
   }
 }
 
-// the arrow block: AA' = AA - sum over ALL blocks e of U_aa(e) (block 0 included: it was eliminated last), dense Cholesky with the
-// rhs row carried along, x_arrow.  512 threads gather (one wave per entry, the blocks over the lanes, summed with a fixed
-// butterfly: reproducible), wave 0 factors and solves in LDS (NA <= 31).
+// the arrow block: AA' = AA - sum over ALL blocks e of U_aa(e) (block 0 included: it was eliminated last), factored with the same
+// register panel (rows: AA' padded to 4 NQA columns | rhs | identity), x_arrow = L^-T y.  The sum over the blocks runs over the
+// lanes of a wave and ends in a fixed butterfly (reproducible); 16 entries per wave are in flight.
 constexpr uint32_t CR_NA_MAX = 31;
-__global__ __launch_bounds__(512) void k_cr_arrow(CrSys s, CrWs w) {
-  __shared__ double aa[(CR_NA_MAX + 1) * (CR_NA_MAX + 2)], xa[CR_NA_MAX + 1];
-  __shared__ double failf;
-  const uint32_t tid = threadIdx.x, wv = tid >> 6, ln = tid & 63u, NA = s.NA, nax = w.nax, lda = nax + 1;
-  if (tid == 0) failf = 0.0;
-  // entries (a, b), b <= a, b < NA (row NA = rhs): entry t of the wave's list is q = wv + 8 t; eight entries in flight
-  for (uint32_t q0 = wv; q0 < nax * nax; q0 += 64) {
-    double v[8]; uint32_t ab[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const uint32_t q = q0 + 8u * u, a = q / nax, b = q - a * nax;
-      const bool ok = q < nax * nax && b <= a && b < NA;
-      ab[u] = ok ? a * 64u + b : 0xFFFFFFFFu;
-      double sacc = 0.0;
-      for (uint32_t e0 = 0; e0 < w.nb; e0 += 64) {
-        const uint32_t e = e0 + ln;
-        sacc += (ok && e < w.nb) ? w.U[(size_t)e * w.ustride + w.off_aa() + a * nax + b] : 0.0;
-      }
-      v[u] = sacc;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      double t = v[u];
-#pragma unroll
-      for (int sh = 32; sh >= 1; sh >>= 1) t += __shfl_xor(t, sh, 64);
-      if (ab[u] != 0xFFFFFFFFu && ln == 0) { const uint32_t a = ab[u] >> 6, b = ab[u] & 63u; aa[a * lda + b] = s.Sarrow[(size_t)a * s.ld + 6 * s.F + b] - t; }
-    }
+template <int NQA>
+__global__ __launch_bounds__(256) void k_cr_arrow(CrSys s, CrWs w) {
+  constexpr uint32_t NPA = 4 * NQA, ldp = NPA + 1, NRG = 64;
+  __shared__ double pan[(2 * NPA + 1) * (NPA + 1) + 2], cb[2 * (4 * NRG + NPA)];
+  const uint32_t tid = threadIdx.x, ln = tid & 63u, NA = s.NA, nax = w.nax, nrows = NPA + 1 + NA;
+  const uint32_t cp = __builtin_amdgcn_readfirstlane(tid >> 6), rg = ln;
+  for (uint32_t i = tid; i < nrows * ldp; i += 256) { const uint32_t r = i / ldp, c = i - r * ldp; pan[i] = (r < NPA ? r == c : (r > NPA && r - NPA - 1 == c)) ? 1.0 : 0.0; }
+  __syncthreads();
+  const double* aasum = w.x + (size_t)w.nb * w.m + nax;   // blocks 1..nb-1 (k_cr_products, last launch); block 0's share is in U
+  for (uint32_t q = tid; q < nax * nax; q += 256) {
+    const uint32_t a = q / nax, b = q - a * nax;
+    if (b > a || b >= NA) continue;
+    const double val = (s.Sarrow[(size_t)a * s.ld + 6 * s.F + b] - aasum[q]) - w.U[w.off_aa() + q];
+    if (a < NA) { pan[a * ldp + b] = val; pan[b * ldp + a] = val; } else pan[NPA * ldp + b] = val;   // a == NA: the rhs row
   }
   __syncthreads();
-  if (wv != 0) return;
-  // one wave: right-looking Cholesky of the NA x NA block, row NA (the rhs) follows
-  for (uint32_t j = 0; j < NA; ++j) {
-    double piv = aa[j * lda + j];
-    if (!(piv > 0.0)) { piv = 1.0; if (ln == 0) failf = 1.0; }
-    const double is = rsqrt(piv);
-    __builtin_amdgcn_wave_barrier();
-    for (uint32_t r = j + ln; r <= NA; r += 64) aa[r * lda + j] *= is;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const uint32_t nr = NA - j;   // rows j+1..NA
-    for (uint32_t t = ln; t < nr * nr; t += 64) {
-      const uint32_t r = j + 1 + t / nr, c = j + 1 + t % nr;
-      if (c <= r && c < NA) aa[r * lda + c] -= aa[r * lda + j] * aa[c * lda + j];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  double x[4][NQA];
+  cr_panel_load<NQA>(x, pan, ldp, rg, cp, NRG, nrows);
+  const bool fail = cr_panel_factor<NQA>(x, rg, cp, NRG, cb);
+  cr_panel_store<NQA>(x, pan, ldp, rg, cp, NRG, nrows);
+  if (fail) *s.fail = 1.0;
+  __syncthreads();
+  // x = L^-T y: row NPA holds y, rows NPA + 1 + i hold row i of L^-T
+  if (tid < NA) {
+    double sacc = 0.0;
+    for (uint32_t k = tid; k < NA; ++k) sacc += pan[(size_t)(NPA + 1 + tid) * ldp + k] * pan[(size_t)NPA * ldp + k];
+    w.x[(size_t)w.nb * w.m + tid] = sacc; s.delta_red[6 * s.F + tid] = sacc;
   }
-  // L^T x = y (y = row NA)
-  if (ln <= NA) xa[ln] = ln < NA ? aa[NA * lda + ln] : 0.0;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  for (int j = (int)NA - 1; j >= 0; --j) {
-    const double xj = xa[j] / aa[j * lda + j];
-    __builtin_amdgcn_wave_barrier();
-    if (ln == 0) xa[j] = xj;
-    if (ln < (uint32_t)j) xa[ln] -= aa[j * lda + ln] * xj;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  }
-  if (ln < NA) { const double v = xa[ln]; w.x[(size_t)w.nb * w.m + ln] = v; s.delta_red[6 * s.F + ln] = v; }
-  if (ln == 0 && failf != 0.0) *s.fail = 1.0;
 }
 
 // x_e = L^-T (y_e - [P_l; P_r; P_a]^T [x_l; x_r; x_a]) for the blocks eliminated at `level`; 512 threads: 8 row groups x 64 columns
@@ -656,7 +606,7 @@ inline size_t cr_ws_doubles_P(const CrWs& w) { return (size_t)w.nb * w.prow * w.
 inline size_t cr_ws_doubles_D(const CrWs& w) { return (size_t)w.nb * w.m * w.m; }
 inline size_t cr_ws_doubles_A(const CrWs& w) { return (size_t)w.nb * w.nax * w.m; }
 inline size_t cr_ws_doubles_U(const CrWs& w) { return (size_t)w.nb * w.ustride; }
-inline size_t cr_ws_doubles_x(const CrWs& w) { return (size_t)w.nb * w.m + w.nax; }
+inline size_t cr_ws_doubles_x(const CrWs& w) { return (size_t)w.nb * w.m + w.nax + (size_t)w.nax * w.nax; }   // solution | sum of the arrow products of the blocks 1..nb-1
 
 #define CR_FOR_NQ(X) X(3) X(6) X(9) X(12) X(14) X(15)
 
@@ -700,7 +650,7 @@ inline void cr_solve_launch(const CrPlan& p, const CrSys& s, hipStream_t stream)
     CR_FOR_NQ(CR_LAUNCH)
 #undef CR_LAUNCH
     hipLaunchKernelGGL(k_cr_products, dim3(1), dim3(CR_PROD_THREADS), p.prod_lds, stream, s, w, l);
-    hipLaunchKernelGGL(k_cr_arrow, dim3(1), dim3(512), 0, stream, s, w);
+    if (s.NA <= 20) hipLaunchKernelGGL(k_cr_arrow<5>, dim3(1), dim3(256), 0, stream, s, w); else hipLaunchKernelGGL(k_cr_arrow<8>, dim3(1), dim3(256), 0, stream, s, w);
     hipLaunchKernelGGL(k_cr_backsub, dim3(1), dim3(512), 0, stream, s, w, l);
   }
   for (int l = (int)w.levels - 1; l >= 0; --l) {

@@ -10,8 +10,8 @@ for name in sys.argv[1:] or ["cfg2", "cfg3", "metric"]:
     t = time.time(); ba = BundleAdjustment(pa); tc = time.time() - t
     t = time.time(); s = ba.performBundleAdjustment(); tg = time.time() - t
     st = ba.calcReprojectionError()
-    print(f"{name}: N={sc.n_obs} create {tc:.3f}s solve {tg:.3f}s it {s.iterations} ({s.successful_steps}+{s.unsuccessful_steps}) cost {s.initial_cost:.6e}->{s.final_cost:.6e} term {s.termination} "
-          f"sweep {s.seconds_sweep:.3f}s linear+candidate {s.seconds_linear_solve:.3f}s rms ({st.std_x:.4f},{st.std_y:.4f}) inliers {st.num_inliers}/{st.num_points}")
+    print(f"{name}: N={sc.n_obs} create {tc:.3f}s solve {1e3*tg:.2f} ms it {s.iterations} ({s.successful_steps}+{s.unsuccessful_steps}) cost {s.initial_cost:.6e}->{s.final_cost:.6e} term {s.termination} "
+          f"sweep {1e3*s.seconds_sweep:.3f} ms linear+candidate {1e3*s.seconds_linear_solve:.3f} ms ({1e3*s.seconds_linear_solve/max(1,s.iterations-1):.3f} per iteration) rms ({st.std_x:.4f},{st.std_y:.4f}) inliers {st.num_inliers}/{st.num_points}")
     if name in ("cfg2", "cfg3"):
         pb = capi.ProblemArrays.from_scene(sc)
         t = time.time(); so = oracle.solve(pb, threads=oracle.hardware_threads()); to = time.time() - t
