@@ -35,6 +35,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -76,10 +77,9 @@ inline int cr_factor_nq(uint32_t m) {
   for (int nq : {3, 6, 9, 12, 14, 15}) if (nq >= need) return nq;
   return 0;
 }
-inline uint32_t cr_threads(uint32_t nrows) { return 256u * ((nrows + 255u) / 256u); }   // four rows per thread, four column parts
+inline uint32_t cr_threads(uint32_t nrows) { return nrows <= 256 ? 512u : 1024u; }   // 512 threads: two rows per thread (nrows <= 256), four column parts
 inline size_t cr_factor_lds(uint32_t nrows, int NQ) {
-  const uint32_t nrg = cr_threads(nrows) / 4;
-  return ((size_t)nrows * (4 * NQ + 1) + 2 + 2 * (4 * (size_t)nrg + 4 * (size_t)NQ) + 8) * sizeof(double);
+  return ((size_t)nrows * (4 * NQ + 1) + 2 + 2 * (256 + 4 * (size_t)NQ) + 8) * sizeof(double);   // panel | two column buffers (256 rows + the permuted block part)
 }
 inline size_t cr_products_lds(const CrWs& w) {   // k-major operand copies, row strides 80 (<= 64 rows) and 48 (<= 32 rows) doubles
   const size_t mk = (w.m + 3u) & ~3u;
@@ -91,7 +91,7 @@ inline bool cr_eligible(uint32_t F, uint32_t bw, uint32_t NA) {
   const int nq = cr_factor_nq(w.m);
   if (w.nb < 4 || nq == 0) return false;
   const uint32_t nrows = 4 * nq + w.prow;
-  return cr_factor_lds(nrows, nq) <= 160 * 1024 && cr_threads(nrows) <= 512 && cr_products_lds(w) <= 160 * 1024;
+  return cr_factor_lds(nrows, nq) <= 160 * 1024 && nrows <= 256 && cr_products_lds(w) <= 160 * 1024;
 }
 __host__ __device__ inline uint32_t cr_n_active(uint32_t nb, uint32_t level) { return ((nb - 1) >> level) + 1; }   // multiples of 2^level below nb
 inline uint32_t cr_n_elim(uint32_t nb, uint32_t level) { return cr_n_active(nb, level) / 2; }                        // the odd ones
@@ -135,21 +135,20 @@ LIFCAL_DEV CrSrc cr_src_S(const CrSys& s, uint32_t fi, uint32_t a, uint32_t fj, 
 // shifted down after every quad and a fall-through switch over the live quads (AGPR traffic: 97 us per panel).
 // (Measured and dropped: deferring the updates nobody waits for behind the next barrier, so that they run under the next
 // column's LDS reads — same time, 36 more registers: the step is bound by instruction issue of the single wave per SIMD.)
-template <int NQ>
-LIFCAL_DEV bool cr_panel_factor(double (&x)[4][NQ], uint32_t rg, uint32_t cp, uint32_t NRG, double* cb) {
+template <int NQ, int RT>
+LIFCAL_DEV bool cr_panel_factor(double (&x)[RT][NQ], uint32_t rg, uint32_t cp, uint32_t NRG, double* cb) {
   constexpr uint32_t NC = 4 * NQ;
-  const uint32_t NAT = 4 * NRG, BS = NAT + NC;
+  const uint32_t NAT = RT * NRG, BS = NAT + NC;
   bool fail = false;
-  auto write_col = [&](double* buf, double v0, double v1, double v2, double v3) {
-    const double v[4] = {v0, v1, v2, v3};
+  auto write_col = [&](double* buf, int k) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const uint32_t r = rg + (uint32_t)i * NRG;
-      buf[r] = v[i];
-      if (r < NC) buf[NAT + (r & 3u) * NQ + (r >> 2)] = v[i];
+      buf[r] = x[i][k];
+      if (r < NC) buf[NAT + (r & 3u) * NQ + (r >> 2)] = x[i][k];
     }
   };
-  if (cp == 0) write_col(cb, x[0][0], x[1][0], x[2][0], x[3][0]);
+  if (cp == 0) write_col(cb, 0);
   const uint32_t segoff = NAT + cp * NQ;
   cr_static_for<0, NQ>([&](auto clc) {
     constexpr int cl = decltype(clc)::value;
@@ -159,9 +158,9 @@ LIFCAL_DEV bool cr_panel_factor(double (&x)[4][NQ], uint32_t rg, uint32_t cp, ui
       double* buf = cb + (j & 1u) * BS;
       cr_lds_barrier();
       double piv = buf[NAT + cpj * NQ + cl];
-      double rj[4];
+      double rj[RT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) rj[i] = buf[rg + (uint32_t)i * NRG];
+      for (int i = 0; i < RT; ++i) rj[i] = buf[rg + (uint32_t)i * NRG];
       const double* seg = buf + segoff;
       double cv[NQ];
       cr_static_for<cl, NQ>([&](auto kc) { constexpr int k = decltype(kc)::value; cv[k] = seg[k]; });
@@ -169,28 +168,28 @@ LIFCAL_DEV bool cr_panel_factor(double (&x)[4][NQ], uint32_t rg, uint32_t cp, ui
       const double is = rsqrt(piv), inv = is * is;
       // quad cl: the columns left of the pivot (and the pivot column) are final — their waves multiply by 0
       const double own = cp > (uint32_t)cpj ? 1.0 : 0.0;
-      double a[4];
+      double a[RT];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = rj[i] * inv;
+      for (int i = 0; i < RT; ++i) a[i] = rj[i] * inv;
       constexpr int cl1 = (cpj == 3) ? cl + 1 : cl;       // the next pivot column: quad cl1 of column part cp1
       constexpr uint32_t cp1 = (cpj + 1) & 3;
       if constexpr (cl1 < NQ) {   // its quad goes first: it is what every wave waits for
         const double f1 = (cl1 == cl) ? own : 1.0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[i][cl1] -= (a[i] * f1) * cv[cl1];
-        if (cp == cp1) write_col(cb + ((j + 1u) & 1u) * BS, x[0][cl1], x[1][cl1], x[2][cl1], x[3][cl1]);
+        for (int i = 0; i < RT; ++i) x[i][cl1] -= (a[i] * f1) * cv[cl1];
+        if (cp == cp1) write_col(cb + ((j + 1u) & 1u) * BS, cl1);
       }
       cr_static_for<cl, NQ>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         if constexpr (k != cl1) {
           const double fk = (k == cl) ? own : 1.0;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) x[i][k] -= (a[i] * fk) * cv[k];
+          for (int i = 0; i < RT; ++i) x[i][k] -= (a[i] * fk) * cv[k];
         }
       });
       if (cp == (uint32_t)cpj) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[i][cl] = rj[i] * is;
+        for (int i = 0; i < RT; ++i) x[i][cl] = rj[i] * is;
       }
       // the updated entries are pinned here (an empty asm that "modifies" them): left alone, the optimiser sinks the updates
       // of a column down to their first use, several columns later, and keeps every (a, column value) pair alive until then —
@@ -198,7 +197,7 @@ LIFCAL_DEV bool cr_panel_factor(double (&x)[4][NQ], uint32_t rg, uint32_t cp, ui
       cr_static_for<cl, NQ>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) cr_pin(x[i][k]);
+        for (int i = 0; i < RT; ++i) cr_pin(x[i][k]);
       });
     });
   });
@@ -207,19 +206,19 @@ LIFCAL_DEV bool cr_panel_factor(double (&x)[4][NQ], uint32_t rg, uint32_t cp, ui
 }
 
 // registers <-> LDS panel pan[r * ldp + c]
-template <int NQ>
-LIFCAL_DEV void cr_panel_load(double (&x)[4][NQ], const double* pan, uint32_t ldp, uint32_t rg, uint32_t cp, uint32_t NRG, uint32_t nrows) {
+template <int NQ, int RT>
+LIFCAL_DEV void cr_panel_load(double (&x)[RT][NQ], const double* pan, uint32_t ldp, uint32_t rg, uint32_t cp, uint32_t NRG, uint32_t nrows) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RT; ++i) {
     const uint32_t r = rg + (uint32_t)i * NRG;
 #pragma unroll
     for (int cl = 0; cl < NQ; ++cl) x[i][cl] = (r < nrows) ? pan[(size_t)r * ldp + 4u * cl + cp] : 0.0;
   }
 }
-template <int NQ>
-LIFCAL_DEV void cr_panel_store(const double (&x)[4][NQ], double* pan, uint32_t ldp, uint32_t rg, uint32_t cp, uint32_t NRG, uint32_t nrows) {
+template <int NQ, int RT>
+LIFCAL_DEV void cr_panel_store(const double (&x)[RT][NQ], double* pan, uint32_t ldp, uint32_t rg, uint32_t cp, uint32_t NRG, uint32_t nrows) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RT; ++i) {
     const uint32_t r = rg + (uint32_t)i * NRG;
 #pragma unroll
     for (int cl = 0; cl < NQ; ++cl) if (r < nrows) pan[(size_t)r * ldp + 4u * cl + cp] = x[i][cl];
@@ -321,12 +320,13 @@ __global__ __launch_bounds__(TPB) void k_cr_factor(CrSys s, CrWs w, uint32_t lev
   }
   __syncthreads();
   CRSTAMP(1);
-  double x[4][NQ];
-  cr_panel_load<NQ>(x, pan, ldp, rg, cp, NRG, nrows);
+  constexpr int RT = TPB == 512 ? 2 : 4;   // rows per thread: 512 threads = two waves per SIMD, half the rows each
+  double x[RT][NQ];
+  cr_panel_load<NQ, RT>(x, pan, ldp, rg, cp, NRG, nrows);
   CRSTAMP(2);
-  const bool fail = cr_panel_factor<NQ>(x, rg, cp, NRG, cb);
+  const bool fail = cr_panel_factor<NQ, RT>(x, rg, cp, NRG, cb);
   CRSTAMP(3);
-  cr_panel_store<NQ>(x, pan, ldp, rg, cp, NRG, nrows);
+  cr_panel_store<NQ, RT>(x, pan, ldp, rg, cp, NRG, nrows);
   if (fail) *s.fail = 1.0;
   __syncthreads();
   double* out = w.P + (size_t)e * w.prow * m;
@@ -525,9 +525,9 @@ __global__ __launch_bounds__(256) void k_cr_arrow(CrSys s, CrWs w) {
   }
   __syncthreads();
   double x[4][NQA];
-  cr_panel_load<NQA>(x, pan, ldp, rg, cp, NRG, nrows);
-  const bool fail = cr_panel_factor<NQA>(x, rg, cp, NRG, cb);
-  cr_panel_store<NQA>(x, pan, ldp, rg, cp, NRG, nrows);
+  cr_panel_load<NQA, 4>(x, pan, ldp, rg, cp, NRG, nrows);
+  const bool fail = cr_panel_factor<NQA, 4>(x, rg, cp, NRG, cb);
+  cr_panel_store<NQA, 4>(x, pan, ldp, rg, cp, NRG, nrows);
   if (fail) *s.fail = 1.0;
   __syncthreads();
   // x = L^-T y: row NPA holds y, rows NPA + 1 + i hold row i of L^-T
@@ -619,6 +619,7 @@ inline bool cr_plan(CrPlan& p, uint32_t F, uint32_t bw, uint32_t NA) {
   p.nq = cr_factor_nq(m);
   const uint32_t nrows = 4 * p.nq + p.ws.prow;
   p.fac_threads = cr_threads(nrows);
+  if (const char* ev = getenv("LIFCAL_CR_THREADS")) { if (atoi(ev) == 256) p.fac_threads = 256; }   // A/B: one wave per SIMD, four rows per thread
   p.fac_lds = cr_factor_lds(nrows, p.nq); p.fin_lds = 0;
   p.prod_lds = cr_products_lds(p.ws);
   hipError_t rc = hipSuccess;
