@@ -193,14 +193,15 @@ int lifcal_ba_sweep(lifcal_ba_handle* h, double radius, lifcal_ba_sweep_out* out
  * result later with lifcal_ba_sweep, or synchronise the stream).  Used for back-to-back timing. */
 int lifcal_ba_sweep_enqueue(lifcal_ba_handle* h, double radius);
 
-/* HIP-event instrumentation of the sweep kernels, recorded on the stream the kernels run on.
- * begin() reserves event pairs for up to max_sweeps sweeps; end() synchronises and averages. */
+/* HIP-event instrumentation of the sweeps on the stream the kernels run on.  The dominant kernel carries its own start / stop
+ * events (written by its dispatch packet: no extra barrier packets in the queue); one record opens the span before the first
+ * profiled sweep, one closes it behind the last.  begin() reserves events for up to max_sweeps sweeps; end() synchronises and averages. */
 typedef struct lifcal_ba_profile {
   uint32_t n_sweeps;
-  double ms_tables;       /* k_tables: camera constants + frame table + lens table + zero fill of the reduced block   */
+  double ms_tables;       /* 0 (the table kernel is no longer timed separately: it is part of ms_schur)                 */
   double ms_accumulate;   /* the dominant kernel(s): k_sweep3 (fused residual + Jacobian + accumulation + point elimination
                              of the regular points) [+ k_sweep for special points]                                    */
-  double ms_schur;        /* everything behind it: constraints, k_schur (special points), exchange, k_finalize         */
+  double ms_schur;        /* ms_total - ms_accumulate: tables, special points, constraints, exchange, k_finalize, gaps  */
   double ms_total;        /* first kernel of the first sweep to the end of the last one, divided by the sweep count    */
 } lifcal_ba_profile;
 int lifcal_ba_profile_begin(lifcal_ba_handle* h, uint32_t max_sweeps);

@@ -8,6 +8,7 @@
 // restated): radius 1e4, accept if rho > 1e-3, radius /= max(1/3, 1-(2 rho-1)^3), reject: radius /= 2^k,
 // Jacobi scaling fixed at iteration 0, LM diagonal clamp [1e-6, 1e32].
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <dlfcn.h>
 
@@ -111,7 +112,7 @@ struct lifcal_ba_handle {
   CrPlan cr; bool use_cr = false;   // block odd-even reduction (bandchol3.hpp): long sequences
   bool twisted = false; uint32_t tw_m = 0; double *dumpA = nullptr, *dumpB = nullptr;   // two-ended factorisation (bandchol2.hpp): frames [0, tw_m) | bw middle frames | the rest
   // profiling: 5 events per sweep (start, after tables, after k_sweep, before k_schur, after k_schur, end)
-  std::vector<hipEvent_t> prof_events; uint32_t prof_cap = 0, prof_used = 0; bool prof_on = false;
+  std::vector<hipEvent_t> prof_events; uint32_t prof_cap = 0, prof_used = 0; bool prof_on = false, prof_closed = false;
   hipEvent_t prof_ev(int which) { return prof_events[(size_t)prof_used * 6 + which]; }
   bool prof_active() const { return prof_on && prof_used < prof_cap; }
 };
@@ -212,33 +213,39 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
   Dev& d = h->d;
   if (!zeroed) HIP_TRY(hipMemsetAsync(h->red_block, 0, h->red_count * sizeof(double), h->stream));
   if (d.n_special) hipLaunchKernelGGL(k_zero_special, dim3((d.n_special * 36 + 255) / 256), dim3(256), 0, h->stream, d);
-  if (mode == 0 && h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(1), h->stream));
+  // profiling: the dominant kernel carries its own start / stop events (hipExtLaunchKernelGGL: the time stamps are written by the
+  // kernel's dispatch packet itself) — event records around it are separate barrier packets, ~2 us of idle queue each, four per sweep
+  const bool prof = mode == 0 && h->prof_active();
+  hipEvent_t ev_a = prof ? h->prof_ev(1) : nullptr, ev_b = prof ? h->prof_ev(2) : nullptr;
   if (d.n_blocks) {   // regular points: LDS-window kernel, one workgroup per block
-#define CALL_SWEEP2(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep2<NR, TAN, ADJ>), dim3(d.n_blocks), dim3(256), h->v2_lds_bytes, h->stream, d, radius, mode)
-#define CALL_SWEEP3(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep3<NR, TAN, ADJ, 4>), dim3(d.n_blocks), dim3(512), h->v2_lds_bytes, h->stream, d, radius, mode)
-#define CALL_SWEEP3F(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep3<NR, TAN, ADJ, 4, float>), dim3(d.n_blocks), dim3(512), h->v2_lds_bytes, h->stream, d, radius, mode)
-#define CALL_SWEEP3H(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep3<NR, TAN, ADJ, 2>), dim3(d.n_blocks), dim3(256), h->v2_lds_bytes, h->stream, d, radius, mode)
+    hipEvent_t ev_stop = d.deterministic ? nullptr : ev_b;   // (deterministic: the slab reduction below belongs to the dominant work)
+#define LAUNCH_DOM(KERNEL, THREADS) hipExtLaunchKernelGGL(KERNEL, dim3(d.n_blocks), dim3(THREADS), h->v2_lds_bytes, h->stream, ev_a, ev_stop, 0, d, radius, mode)
+#define CALL_SWEEP2(NR, TAN, ADJ) LAUNCH_DOM((k_sweep2<NR, TAN, ADJ>), 256)
+#define CALL_SWEEP3(NR, TAN, ADJ) LAUNCH_DOM((k_sweep3<NR, TAN, ADJ, 4>), 512)
+#define CALL_SWEEP3F(NR, TAN, ADJ) LAUNCH_DOM((k_sweep3<NR, TAN, ADJ, 4, float>), 512)
+#define CALL_SWEEP3H(NR, TAN, ADJ) LAUNCH_DOM((k_sweep3<NR, TAN, ADJ, 2>), 256)
     if (h->opt.precision == 1) DISPATCH_CFG(h, CALL_SWEEP3F);
     else if (h->use_sweep3 && h->sweep_waves == 2) DISPATCH_CFG(h, CALL_SWEEP3H); else if (h->use_sweep3) DISPATCH_CFG(h, CALL_SWEEP3); else DISPATCH_CFG(h, CALL_SWEEP2);
 #undef CALL_SWEEP3H
 #undef CALL_SWEEP3F
     if (d.deterministic) {   // ordered sum of the per-block window slabs instead of the kernel's atomic flush
-      const V2Lds lay(d.v2_nfmax, true, 256);
-      (void)lay;
       const uint32_t NCd = d.nc, F6 = 6 * d.F;
       const uint64_t n = (uint64_t)d.F * (d.bw + 1) * 36 + (uint64_t)NCd * F6 + NCd * (NCd + 1) / 2 + 3ull * F6 + 3ull * NCd + 3;
       hipLaunchKernelGGL(k_det_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, d, mode);
-      hipLaunchKernelGGL(k_det_reduce_all, dim3(NCd * (NCd + 1) / 2 + 3 * NCd + 3), dim3(64), 0, h->stream, d, mode);
+      hipExtLaunchKernelGGL(k_det_reduce_all, dim3(NCd * (NCd + 1) / 2 + 3 * NCd + 3), dim3(64), 0, h->stream, nullptr, ev_b, 0, d, mode);
     }
 #undef CALL_SWEEP3
 #undef CALL_SWEEP2
+#undef LAUNCH_DOM
+  } else if (prof) {   // no LDS-window blocks (special arities): bracket the fallback kernels with records
+    HIP_TRY(hipEventRecord(ev_a, h->stream));
   }
   if (d.n_tiles) {    // special points (constraints, promoted, oversized, camera-only / pose-only arities): global atomics
 #define CALL_SWEEP(NR, TAN, ADJ) hipLaunchKernelGGL((k_sweep<NR, TAN, ADJ>), dim3(sweep_grid(h)), dim3(256), 0, h->stream, d)
     DISPATCH_CFG(h, CALL_SWEEP);
 #undef CALL_SWEEP
   }
-  if (mode == 0 && h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(2), h->stream));
+  if (prof && !d.n_blocks) HIP_TRY(hipEventRecord(ev_b, h->stream));
   if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 0, (const double*)d.pts, d.scal + SCAL_COST);
   if (d.Q && d.use_points) hipLaunchKernelGGL(k_promote_diag, dim3((d.Q + 63) / 64), dim3(64), 0, h->stream, d);
   HIP_TRY(hipGetLastError());
@@ -248,7 +255,7 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
 // one Jacobian + Schur sweep at the current point and the given trust-region radius
 int launch_sweep(lifcal_ba_handle* h, double radius) {
   Dev& d = h->d;
-  if (h->prof_active()) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));
+  if (h->prof_active() && h->prof_used == 0) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));   // the span opens with the first profiled sweep ...
   // the table kernel also zero-fills the reduced block and the step scalars
   if (int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true, h->red_block, h->red_count, d.step, ST_N, d.ltf)) return rc;
   bool zeroed = true;
@@ -275,7 +282,10 @@ int launch_sweep(lifcal_ba_handle* h, double radius) {
   if (int rc = exchange_reduced(h)) return rc;
   hipLaunchKernelGGL(k_finalize, dim3((d.n_red + 255) / 256), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
-  if (h->prof_active()) { HIP_TRY(hipEventRecord(h->prof_ev(5), h->stream)); h->prof_used++; }   // event 5 of the LAST sweep closes the timed span
+  if (h->prof_active()) {   // ... and closes with the last one (a record per sweep is a barrier packet per sweep)
+    if (h->prof_used + 1 == h->prof_cap) { HIP_TRY(hipEventRecord(h->prof_ev(5), h->stream)); h->prof_closed = true; }
+    h->prof_used++;
+  }
   return 0;
 }
 
@@ -906,27 +916,28 @@ int lifcal_ba_profile_begin(lifcal_ba_handle* h, uint32_t max_sweeps) {
   if (!h) return LIFCAL_BA_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->opt.device));
   while (h->prof_events.size() < (size_t)max_sweeps * 6) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->prof_events.push_back(e); }
-  h->prof_cap = max_sweeps; h->prof_used = 0; h->prof_on = true;
+  h->prof_cap = max_sweeps; h->prof_used = 0; h->prof_on = true; h->prof_closed = false;
   return 0;
 }
 
 int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out) {
   if (!h || !out) return LIFCAL_BA_ERR_INVALID_ARG;
+  const uint32_t n = h->prof_used;
+  if (n && !h->prof_closed) HIP_TRY(hipEventRecord(h->prof_events[(size_t)(n - 1) * 6 + 5], h->stream));   // fewer sweeps than reserved: close the span now
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::memset(out, 0, sizeof(*out));
-  const uint32_t n = h->prof_used;
-  for (uint32_t i = 0; i < n; ++i) {   // per sweep: events 0 | tables + zero fill | 1 | dominant kernel(s) | 2 | everything after it | 5
-    float a = 0, bms = 0, c = 0;
+  for (uint32_t i = 0; i < n; ++i) {   // per sweep: the dominant kernel's own start / stop stamps (events 1, 2)
+    float bms = 0;
     hipEvent_t* e = &h->prof_events[(size_t)i * 6];
-    HIP_TRY(hipEventElapsedTime(&a, e[0], e[1]));
     HIP_TRY(hipEventElapsedTime(&bms, e[1], e[2]));
-    HIP_TRY(hipEventElapsedTime(&c, e[2], e[5]));
-    out->ms_tables += a; out->ms_accumulate += bms; out->ms_schur += c;
+    out->ms_accumulate += bms;
   }
   if (n) {
     float t = 0;   // first kernel of the first sweep -> end of the last sweep (includes the gaps between sweeps)
     HIP_TRY(hipEventElapsedTime(&t, h->prof_events[0], h->prof_events[(size_t)(n - 1) * 6 + 5]));
-    out->ms_total = t / n; out->ms_accumulate /= n; out->ms_tables /= n; out->ms_schur /= n;
+    out->ms_total = t / n; out->ms_accumulate /= n;
+    out->ms_tables = 0.0;                                   // (not separated any more: it would take a barrier packet per sweep)
+    out->ms_schur = out->ms_total - out->ms_accumulate;     // everything outside the dominant kernel: tables, finalize, special points, exchange, launch gaps
   }
   out->n_sweeps = n;
   h->prof_on = false;
