@@ -249,3 +249,28 @@ def test_shard_local_problems_give_the_whole_problem_result(built, tmp_path):
     stt = oracle.reproj_stats(capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, rs[0]["cam"], rs[0]["views"], rs[0]["pts"], sc.spx, sc.scale, sc.config))
     for r in rs:
         assert abs(float(r["stats"][0]) - stt.std_x) < 1e-9 and int(r["stats"][2]) == sc.n_obs and abs(float(r["stats"][4]) - stt.mae_x) < 1e-9
+
+
+def test_block_reduction_is_replicated_bitwise_across_ranks(built, tmp_path, monkeypatch):
+    """bandchol3.hpp under world size 3: every rank factors the same all-reduced system with the block odd-even reduction (forced:
+    the scene has 14 super-blocks) — no atomics, one writer per block, fixed summation orders — so the replicated step, and with
+    it every host decision, must be IDENTICAL on all ranks; the trajectory is the single-process oracle's."""
+    import oracle
+    from lifcal_amd import scene
+    from tests.helpers import free_port
+    monkeypatch.setenv("LIFCAL_CR", "1")
+    spec_kw = dict(n_frames=40, n_points=260, window=4, config=0xF06, seed=1460, outlier_fraction=0.02)
+    mp.spawn(_worker, args=(3, free_port(), str(tmp_path), spec_kw, "allgather"), nprocs=3, join=True)
+    pb = capi_problem(scene.make_scene(scene.SceneSpec(**spec_kw)))
+    so = oracle.solve(pb, threads=4)
+    rs = [np.load(os.path.join(str(tmp_path), f"rank{r}.npz")) for r in range(3)]
+    for rr in rs:
+        assert (int(rr["it"]), int(rr["term"])) == (so.iterations, so.termination)
+        assert abs(float(rr["final"]) - so.final_cost) <= 1e-8 * so.final_cost
+        assert np.array_equal(rr["cam"], rs[0]["cam"]) and np.array_equal(rr["views"], rs[0]["views"])
+    assert np.allclose(rs[0]["cam"][:5], pb.cam[:5], rtol=1e-6)
+
+
+def capi_problem(sc):
+    from lifcal_amd import _capi as capi
+    return capi.ProblemArrays.from_scene(sc)
