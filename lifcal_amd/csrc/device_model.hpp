@@ -451,6 +451,86 @@ LIFCAL_DEV void obs_eval2f(const CamF& c, const GroupConsts2F& g, const float* _
   for (int j = 0; j < NC; ++j) { Jc[0][j] = dx[j] * s0; Jc[1][j] = dy[j] * s1; }
 }
 
+// ---- the same evaluation in PACKED fp32 (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two floats per lane and instruction) ----
+// The model is a chain of (x, y) pairs — lens offset w, direction q, micro-image point, every Jacobian column (dx[i], dy[i]),
+// the row factors (1/sp_x, 1/sp_y) — so the pairs live in <2 x float> values and one packed instruction does both components:
+// about 85 vector instructions per observation instead of about 180.  Same operations in the same order as obs_eval2f (the
+// results agree to the last bit wherever the compiler contracts the same multiply-adds).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+LIFCAL_DEV f32x2 pk(float a, float b) { f32x2 r; r.x = a; r.y = b; return r; }
+LIFCAL_DEV f32x2 pk1(float a) { f32x2 r; r.x = a; r.y = a; return r; }
+template <int NR, bool TAN, bool ADJ>
+LIFCAL_DEV void obs_eval2f_pk(const CamF& c, const GroupConsts2F& g, const float* __restrict__ L, double w64x, double w64y, float du, float dv, bool robust,
+                              float r[2], float Jq[2][3], float Jc[2][5 + NR + (TAN ? 2 : 0)], float& arg) {
+  constexpr int NA = 2 + NR + (TAN ? 2 : 0);
+  constexpr int NC = 3 + NA;
+  const f32x2 w = pk(L[0], L[1]);
+  const f32x2 q = (pk(g.X, g.Y) + w * c.e) * g.iZq;
+  const f32x2 ml = q * c.gamma - w * c.beta;
+  f32x2 d[NC];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) d[i] = q * g.kq[i] + w * g.kc[i];
+#pragma unroll
+  for (int a = 0; a < NA; ++a) d[3 + a] = pk(L[4 + 2 * a], L[5 + 2 * a]) * g.gl;
+  const f32x2 qZ = q * (-g.gz);
+  f32x2 jd, jo, j2;   // (j00, j11), (j01, j10), (j02, j12)
+  // residual: pMl / sp from the fp64 difference (see obs_eval2f); ml (plain fp32) only feeds the distortion argument
+  f32x2 rr = pk(g.mgx, g.mgy) * pk((float)(w64x - g.w0x), (float)(w64y - g.w0y)) - pk(du, dv);
+  if (ADJ) {
+    rr += pk(L[2], L[3]);
+    if (NR > 0 || TAN) {
+      const f32x2 p = ml + w;
+      const f32x2 pp = p * p;
+      const float r2 = pp.x + pp.y, r4 = r2 * r2, xy = p.x * p.y;
+      float gg = 0.f, gp = 0.f;
+      if (NR >= 1) { gg = c.k0 * r2; gp = c.k0; }
+      if (NR >= 2) { gg += c.k1 * r4; gp += 2.f * c.k1 * r2; }
+      f32x2 dd = p * gg;                                  // Delta
+      f32x2 Ad = pk1(gg) + pp * (2.f * gp);               // (A00, A11)
+      float Ao = 2.f * xy * gp;                           // A01 = A10
+      const f32x2 pT = pk(c.p0, c.p1), pS = pk(c.p1, c.p0);
+      if (TAN) {
+        dd += pT * (pk1(r2) + pp * 2.f) + pS * (2.f * xy);
+        Ad += pT * p * 6.f + pS * pk(p.y, p.x) * 2.f;
+        Ao += 2.f * c.p0 * p.y + 2.f * c.p1 * p.x;
+      }
+      const f32x2 bd = pk1(1.f) + Ad;                     // (b00, b11); b01 = b10 = Ao
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {
+        f32x2 e = pk1(0.f);
+        if (NR >= 1 && i == 5) e = p * r2;
+        if (NR >= 2 && i == 6) e = p * r4;
+        if (TAN && i == 5 + NR) e = pk(r2 + 2.f * pp.x, 2.f * xy);
+        if (TAN && i == 6 + NR) e = pk(2.f * xy, r2 + 2.f * pp.y);
+        d[i] = bd * d[i] + pk(d[i].y, d[i].x) * Ao + e;
+      }
+      jd = bd * g.gz; jo = pk1(Ao * g.gz);
+      j2 = bd * qZ + pk(qZ.y, qZ.x) * Ao;
+      rr += dd * pk(c.isp0, c.isp1);
+    } else {
+      jd = pk1(g.gz); jo = pk1(0.f); j2 = qZ;
+    }
+    d[3].x += c.sp0; d[4].y += c.sp1;
+  } else {
+    jd = pk1(g.gz); jo = pk1(0.f); j2 = qZ;
+  }
+  const f32x2 r2v = rr * rr;
+  const float sq = r2v.x + r2v.y;
+  f32x2 sv = pk(c.isp0, c.isp1);
+  if (robust) {
+    arg = 1.f + sq * c.loss_c;
+    const float sc = rsqrtf(arg);
+    rr *= sc; sv *= sc;
+  } else {
+    arg = sq;
+  }
+  r[0] = rr.x; r[1] = rr.y;
+  const f32x2 a0 = jd * sv, a1 = jo * sv, a2 = j2 * sv;
+  Jq[0][0] = a0.x; Jq[1][1] = a0.y; Jq[0][1] = a1.x; Jq[1][0] = a1.y; Jq[0][2] = a2.x; Jq[1][2] = a2.y;
+#pragma unroll
+  for (int j = 0; j < NC; ++j) { const f32x2 t = d[j] * sv; Jc[0][j] = t.x; Jc[1][j] = t.y; }
+}
+
 // the fp32 lens-table row from the fp64 one (k_tables), and w in fp64 for the side table
 template <bool ADJ>
 LIFCAL_DEV void lens_row_to_float(const CamConsts& c, const double* row, float* out, double* w64) {

@@ -342,7 +342,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
           for (int i = 0; i < LENS_STRIDE; ++i) L[i] = Ln[i];
           ET r[2], Jq[2][3], Jc[2][NC];
           ET arg;
-          if constexpr (F32) obs_eval2f<NR, TAN, ADJ>(cf, gcn, L, wn0, wn1, u, v, d.robust != 0, r, Jq, Jc, arg);
+          if constexpr (F32) obs_eval2f_pk<NR, TAN, ADJ>(cf, gcn, L, wn0, wn1, u, v, d.robust != 0, r, Jq, Jc, arg);   // packed fp32 (obs_eval2f: the scalar form)
           else obs_eval2<NR, TAN, ADJ>(c, gcn, L, u, v, d.robust != 0, r, Jq, Jc, arg);
           // hand-off to the accumulator wave, [value][lane]
 #pragma unroll

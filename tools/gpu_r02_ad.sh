@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 2, call AD: packed fp32 evaluation (options.precision = 1): tests, bench
+set -o pipefail
+mkdir -p gpurun_out/r02
+timeout -k 10 900 python -m pytest tests/test_gpu_precision1.py tests/test_gpu_deterministic.py -x -q -m gpu -p no:cacheprovider > gpurun_out/r02/ad_tests.log 2>&1; rc=$?; echo "tests rc=$rc"; tail -5 gpurun_out/r02/ad_tests.log
+[ $rc -eq 0 ] || exit $rc
+timeout -k 10 900 python -m pytest tests/test_gpu_configs.py tests/test_gpu_windowed.py -x -q -m gpu -p no:cacheprovider > gpurun_out/r02/ad_tests2.log 2>&1; rc=$?; echo "tests2 rc=$rc"; tail -3 gpurun_out/r02/ad_tests2.log
+[ $rc -eq 0 ] || exit $rc
+for arg in "--workload metric_web --precision 1" "--workload metric --precision 1" "--workload metric_web"; do
+  tag=$(echo $arg | tr -d ' -'); timeout -k 10 300 python bench.py --no-cpu-baseline --no-solve $arg > gpurun_out/r02/ad_bench_$tag.json 2> gpurun_out/r02/ad_bench.err; echo "bench $arg rc=$?"
+  python - <<PY
+import json; d=json.load(open("gpurun_out/r02/ad_bench_$tag.json")); r=d["roofline"]; print("$arg: kernel_ms %.4f step ms %.4f value %.3e" % (r["kernel_ms"], d["ms_per_step"], d["value"]))
+PY
+done
