@@ -166,8 +166,9 @@ def test_twisted_band_factorisation_equals_the_single_chain(built, monkeypatch, 
 
 
 @pytest.mark.parametrize("spec", [S(24, 120, 6, 0xF06, 6201, outlier_fraction=0.02), S(60, 400, 8, 0x506, 6202), S(41, 300, 10, 0xF06, 6203, recalib=True, outlier_fraction=0.02),
-                                  S(97, 500, 4, 0xF06, 6204), S(50, 150, 3, 0x706, 6205)],
-                         ids=["w6_f24", "w8_f60", "w10_f41_recalib", "w4_f97", "w3_f50"])
+                                  S(97, 500, 4, 0xF06, 6204), S(50, 150, 3, 0x706, 6205), S(40, 220, 4, 0xF06, 6206, n_constraints=2, outlier_fraction=0.02),
+                                  S(36, 200, 3, 0x506, 6207, n_constraints=4)],
+                         ids=["w6_f24", "w8_f60", "w10_f41_recalib", "w4_f97", "w3_f50", "w4_f40_two_constraints_23_arrow_rows", "w3_f36_four_constraints_29_arrow_rows"])
 def test_block_odd_even_reduction_equals_the_chain(built, monkeypatch, spec):
     """bandchol3.hpp: the block odd-even reduction of the band + arrow system (log2(F / bw) levels, one workgroup per eliminated
     super-block) solves the same reduced system as the chain factorisations: same LM trajectory, same result to the round-off of
