@@ -1157,7 +1157,7 @@ __global__ __launch_bounds__(256) void k_cost(Dev d, TileSet ts, const CamConsts
   const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
   const CamConsts c = *camc;
-  double cost = 0.0;
+  double cost = 0.0, lmant = 1.0; int lexp = 0;
   for (uint32_t tile = wave; tile < ts.n_tiles; tile += n_waves) {
     const uint32_t slot = tile * 64 + lane;
     const uint32_t cnt = ts.slot_cnt[slot];
@@ -1172,17 +1172,35 @@ __global__ __launch_bounds__(256) void k_cost(Dev d, TileSet ts, const CamConsts
       const double Z = ft[6] * P0 + ft[7] * P1 + ft[8] * P2 + ft[11];
       group_prepare(c, X, Y, Z, g);
     }
-    for (uint32_t k = 0; k < kmax; ++k) {
-      if (k < cnt) {
-        const size_t at = ((size_t)row0 + k) * 64 + lane;
-        const double* L = lt_tab + (size_t)ts.ell_lens[at] * LENS_STRIDE;
-        double rx, ry;
-        obs_value<NR, TAN, ADJ>(c, g, L[0], L[1], L[2], L[3], ts.ell_u[at], ts.ell_v[at], rx, ry);
-        const double sq = rx * rx + ry * ry;
-        cost += d.robust ? 0.5 * c.loss_b * log(1.0 + sq * c.loss_c) : 0.5 * sq;
+    // Eight steps at a time, every load of a stage in flight together (clamped rows: unconditional loads): lens indices, then the
+    // four lens values + u, v, then the arithmetic — with a load -> wait -> load chain per step the kernel was two dependent memory
+    // round trips per observation step long (22 us at the metric point for 20 MB of input).  The Cauchy cost is accumulated as a
+    // running mantissa / exponent product, one log per lane at the end (as in k_sweep3).
+    for (uint32_t k0 = 0; k0 < kmax; k0 += 8) {
+      uint32_t li[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) li[q] = ts.ell_lens[((size_t)row0 + min(k0 + (uint32_t)q, kmax - 1)) * 64 + lane];
+      double2 La[8], Lb[8]; double uu[8], vv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const size_t at = ((size_t)row0 + min(k0 + (uint32_t)q, kmax - 1)) * 64 + lane;
+        const double* L = lt_tab + (size_t)li[q] * LENS_STRIDE;
+        La[q] = *reinterpret_cast<const double2*>(L); Lb[q] = *reinterpret_cast<const double2*>(L + 2);
+        uu[q] = ts.ell_u[at]; vv[q] = ts.ell_v[at];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (k0 + (uint32_t)q < cnt) {
+          double rx, ry;
+          obs_value<NR, TAN, ADJ>(c, g, La[q].x, La[q].y, Lb[q].x, Lb[q].y, uu[q], vv[q], rx, ry);
+          const double sq = rx * rx + ry * ry;
+          if (d.robust) { int ex; lmant = frexp(lmant * (1.0 + sq * c.loss_c), &ex); lexp += ex; }
+          else cost += 0.5 * sq;
+        }
       }
     }
   }
+  if (d.robust) cost += 0.5 * c.loss_b * (log(lmant) + (double)lexp * 0.6931471805599453);
   // one global atomic per WORKGROUP: thousands of atomics on one address serialise in L2 (they were most of this kernel's time)
   __shared__ double part[4];
   cost = wave_sum(cost);
