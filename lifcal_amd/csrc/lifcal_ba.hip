@@ -292,8 +292,7 @@ int launch_sweep(lifcal_ba_handle* h, double radius) {
 // read back cost and gradient max-norm of the last accumulate+reduce
 int read_sweep_scalars(lifcal_ba_handle* h, double* cost, double* gmax, double* bad_u) {
   Dev& d = h->d;
-  HIP_TRY(hipMemcpyAsync(h->h_scal, d.scal, SCAL_N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->h_scal + SCAL_N, d.step, ST_N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->h_scal, d.scal, (SCAL_N + ST_N) * sizeof(double), hipMemcpyDeviceToHost, h->stream));   // scal | step: contiguous
   HIP_TRY(hipStreamSynchronize(h->stream));
   *cost = h->h_scal[SCAL_COST];
   *bad_u = h->h_scal[SCAL_BAD_U];
@@ -422,8 +421,7 @@ int eval_trial(lifcal_ba_handle* h, double t, double radius, LsSample* smp) {
 struct StepScalars { double gtd, ddd, step2, x2, cand_cost, chol_fail; };
 
 int read_step_scalars(lifcal_ba_handle* h, StepScalars* s) {
-  HIP_TRY(hipMemcpyAsync(h->h_scal, h->d.step, ST_N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(hipMemcpyAsync(h->h_scal + ST_N, h->partial, 8 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(hipMemcpyAsync(h->h_scal, h->d.step, (ST_N + 8) * sizeof(double), hipMemcpyDeviceToHost, h->stream));   // step | partial: contiguous
   HIP_TRY(hipStreamSynchronize(h->stream));
   const double* a = h->h_scal; const double* p = h->h_scal + ST_N;
   // p[0..3]: all-reduced sums over every rank's points + the replicated camera / pose part contributed by rank 0 alone
@@ -758,7 +756,7 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
   }
   const size_t n_band = (size_t)d.F * (d.bw + 1) * 36, n_arrow = (size_t)(d.NA + 1) * d.ld;
   h->red_count = n_band + n_arrow + 3 * (size_t)d.n_red + SCAL_N;
-  A(h->red_block, h->red_count);
+  A(h->red_block, h->red_count + ST_N + 8);   // ... | scal | step scalars | candidate partial sums: the host reads each pair with ONE copy
   d.Sband = h->red_block; d.Sarrow = d.Sband + n_band; d.rhsacc = d.Sarrow + n_arrow; d.gB = d.rhsacc + d.n_red; d.hdiag = d.gB + d.n_red; d.scal = d.hdiag + d.n_red;
   A(d.sig_red, d.n_red); A(d.lam_red, d.n_red); A(d.delta_red, d.n_red); A(d.Linv, (size_t)d.F * 36 + 36);
   // multi-GPU: slab exchange of the reduced block (every rank's partial block lives in one frame range)
@@ -781,7 +779,8 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
   }
   A(d.dbg, (size_t)std::max(1u, d.n_blocks) * 32);
   A(d.dP, 3 * (size_t)d.P); A(h->ls_buf, 8); A(h->dirmax_buf, 65);
-  A(d.step, ST_N); A(h->partial, 8); A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->stats_slots, 4 + 2 * 64); A(h->pts_gather, 3 * (size_t)d.P);
+  d.step = d.scal + SCAL_N; h->partial = d.step + ST_N;   // (behind the all-reduced block, not part of it)
+  A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->stats_slots, 4 + 2 * 64); A(h->pts_gather, 3 * (size_t)d.P);
   // Cholesky panel: LDS when it fits (<= 64 KiB by default launch limits), else a global scratch
   const size_t panel_rows = 6 * (size_t)d.bw + d.NA + 1;
   const size_t lds_need = (80 + panel_rows * 6) * sizeof(double);
