@@ -81,6 +81,22 @@ def test_random_structures_solve_like_the_oracle(built, k):
     assert abs(sg.final_cost - so.final_cost) <= 1e-7 * max(so.final_cost, 1e-300), tag
 
 
+@pytest.mark.parametrize("k", [3, 7, 17, 19, 27, 33, 42, 44, 54, 58])   # the members of the family the reduction applies to (poses, >= 4 super-blocks)
+def test_random_structures_solve_like_the_oracle_with_the_block_reduction(built, monkeypatch, k):
+    """the same deformed scenes with the reduced solve forced onto the block odd-even reduction (bandchol3.hpp) wherever it is
+    applicable (ragged frame counts, padded last super-block, band widths 1 .. 10; the others fall back to the chains)"""
+    monkeypatch.setenv("LIFCAL_CR", "1")
+    spec, mk, n = deformed_problem(k)
+    if n < 30:
+        pytest.skip("too few observations for a meaningful solve")
+    so = oracle.solve(mk(), threads=4)
+    with BundleAdjustment(mk()) as ba:
+        sg = ba.performBundleAdjustment()
+    tag = f"case {k}: F={spec.n_frames} P={spec.n_points} window={spec.window} cfg={spec.config:#x} n={n}"
+    assert (sg.iterations, sg.termination) == (so.iterations, so.termination), tag
+    assert abs(sg.final_cost - so.final_cost) <= 1e-7 * max(so.final_cost, 1e-300), tag
+
+
 _CHILD = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
