@@ -545,9 +545,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
     if (lane == 63) atomicAdd(misc + 0, cost);
     if (det) publish(turn, my_turn + 1);
     // the accumulator waves reduce the camera block meanwhile: same barriers
-    constexpr int NVB = NCC + NC, RVB = 28;
-#pragma unroll
-    for (int round = 0; round * RVB < NVB; ++round) { lds_barrier(); lds_barrier(); }                   // ---- barriers T1, T2 per round
+    lds_barrier(); lds_barrier();                                                                      // ---- barriers T1, T2
   } else {
     // =====================================================================================================================
     // accumulator waves (threads 256..511): C of the lane, camera x camera block and camera gradient of the thread
@@ -686,30 +684,34 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
         for (int j = 0; j <= i; ++j) cc[t++] *= c.chm[i] * c.chm[j];
       }
     }
-    // 256-way reduction through LDS (k_sweep2's, on the accumulator threads): [value][thread] parked in the free Z region
-    constexpr int NVB = NCC + NC, RVB = 28;
+    // Reduction of the thread's camera x camera block and camera gradient over the accumulator threads: four DPP row shifts leave
+    // the sum of every row of 16 lanes in its lane 15, those 4 WR row sums per value go to the free Z region, one thread per value
+    // adds them up in a fixed order (bitwise reproducible, no atomics: nobody else touches these window entries after barrier T1).
+    // (The 256-way reduction through LDS it replaces — [value][thread], two rounds of 28 values, four barriers — was 4 % of a block.)
+    constexpr int NVB = NCC + NC;
+    constexpr uint32_t NROWS = 4u * WR;   // rows of 16 lanes among the accumulator threads
+    {
+      double* red = Zd;   // [row][NVB]
+      const uint32_t rowi = t256 >> 4;
+      const bool tail = (lane & 15u) == 15u;
 #pragma unroll
-    for (int round = 0; round * RVB < NVB; ++round) {
-#pragma unroll
-      for (int v = 0; v < RVB; ++v) {
-        const int idx = round * RVB + v;
-        if (idx < NVB) Zd[v * (LP + 8) + t256] = (idx < NCC) ? cc[idx < NCC ? idx : 0] : gc[(idx - NCC) >= 0 && (idx - NCC) < NC ? idx - NCC : 0];
+      for (int idx = 0; idx < NVB; ++idx) {
+        double v = (idx < NCC) ? cc[idx < NCC ? idx : 0] : gc[(idx - NCC) >= 0 && (idx - NCC) < NC ? idx - NCC : 0];
+        v = dpp_add_step<0x111, 0xf>(v); v = dpp_add_step<0x112, 0xf>(v); v = dpp_add_step<0x114, 0xf>(v); v = dpp_add_step<0x118, 0xf>(v);
+        if (tail) red[rowi * NVB + idx] = v;
       }
       lds_barrier();                                                                                    // ---- barrier T1
-      constexpr int NPART = (int)LP / 32;   // partial sums per value: 32 entries each
-      if (t256 < RVB * NPART) {
-        const int v = t256 / NPART, part = t256 % NPART, idx = round * RVB + v;
-        if (idx < NVB) {
-          double sacc = 0.0;
-#pragma unroll 8
-          for (int k = 0; k < 32; ++k) sacc += Zd[v * (LP + 8) + part + NPART * k];
-          if (idx < NCC) {
-            int i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i;
-            if (mode == 0) atomicAdd(Scc + idx, sacc);
-            if (idx == i * (i + 1) / 2 + i) atomicAdd(vhd + 6 * NFm + i, sacc);
-          } else {
-            atomicAdd(vgB + 6 * NFm + (idx - NCC), sacc);
-          }
+      if (t256 < (uint32_t)NVB) {
+        const int idx = (int)t256;
+        double sacc = 0.0;
+#pragma unroll
+        for (uint32_t k = 0; k < NROWS; ++k) sacc += red[k * NVB + idx];
+        if (idx < NCC) {
+          int i = 0; while ((i + 1) * (i + 2) / 2 <= idx) ++i;
+          if (mode == 0) Scc[idx] += sacc;
+          if (idx == i * (i + 1) / 2 + i) vhd[6 * NFm + i] += sacc;
+        } else {
+          vgB[6 * NFm + (idx - NCC)] += sacc;
         }
       }
       lds_barrier();                                                                                    // ---- barrier T2
