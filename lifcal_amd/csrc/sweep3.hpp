@@ -536,7 +536,43 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
 #pragma unroll
           for (int j = 0; j < 4; ++j) tacc[i][j] += bt[(i * 4 + j) * LP + tid];
       }
-      emit_tile(mi0, mj0, tacc);
+      // The tile goes into the window with all its LDS reads in flight together: the eight column descriptors, then the sixteen
+      // old values, then the sixteen stores (entries outside the lower triangle / beyond the columns go to a scratch cell of the
+      // thread) — entry by entry (emit_tile) it was sixteen dependent LDS round trips, 2 % of a block.
+      uint32_t ci4[4], cj4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { const uint32_t ci = 4 * mi0 + i, cj = 4 * mj0 + i; ci4[i] = colinfo[ci < ncolp ? ci : 0]; cj4[i] = colinfo[cj < ncolp ? cj : 0]; }
+      uint32_t off[4][4]; double sg[4][4];
+      const uint32_t dummy = lay.off_zd + 1024u + tid;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t ci = 4 * mi0 + i, cj = 4 * mj0 + j, ii = ci4[i], jj = cj4[j];
+          uint32_t o = dummy; double sgn = -1.0;
+          if (!(ci >= ncol || cj >= ncol || ci < cj)) {
+            if (!(ii & 0x8000u)) {            // pose x pose
+              const uint32_t lfi = ii >> 8, lfj = jj >> 8;
+              o = (lfi * (lfi + 1) / 2 + lfj) * 36 + (ii & 0xFFu) * 6 + (jj & 0xFFu);
+            } else if (!(ii & 0x4000u)) {     // camera row
+              const uint32_t jc = ii & 0xFFu;
+              o = !(jj & 0x8000u) ? lay.off_cp + jc * 6 * NFm + cj : lay.off_cc + jc * (jc + 1) / 2 + (jj & 0xFFu);
+            } else if (cj < ncol - 1) {       // rhs row: W^T U^-1 g
+              o = lay.off_vec + 2 * vlen + (!(jj & 0x8000u) ? cj : 6 * NFm + (jj & 0xFFu));
+              sgn = 1.0;
+            }
+          }
+          off[i][j] = o; sg[i][j] = sgn;
+        }
+      double oldv[4][4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) oldv[i][j] = sm[off[i][j]];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm[off[i][j]] = oldv[i][j] + sg[i][j] * tacc[i][j];
     }
     STAMP(9);
     if (d.robust) cost += 0.5 * c.loss_b * (log(lmant) + (double)lexp * 0.6931471805599453);
