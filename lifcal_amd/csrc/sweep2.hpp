@@ -26,6 +26,9 @@ constexpr uint32_t FRV = 27 + 6 * NCMAX;   // frame-level values a group emits: 
 constexpr uint32_t LDS_LIMIT_DOUBLES = 160 * 1024 / 8;
 constexpr uint32_t MISC_DOUBLES = 10;   // misc block of the LDS window: [0] cost [1] bad-U count [2] max |g_p| bits [3] two u32 counters [4..7] eight u32 hand-off counters [8..9] four u32 (deterministic emission turns)
 
+// doubles per point of the per-pass point slab (U 6 | g 3, padded): an ODD stride — with 12 the slabs of points 8 apart start on the
+// same LDS banks and the nine f64 atomics a lane adds to its point's slab ran into 8-way bank conflicts
+constexpr uint32_t SLAB_STRIDE = 13;
 struct V2Lds {
   uint32_t nfm, nrep, np_max, zd, off_cp, off_cc, off_vec, off_fr, off_bt, off_slab, off_zd, off_misc, total;
   // LDS doubles of the dense Z matrix of one pass (and of the hand-off buffer that lives there during the observation loop)
@@ -42,14 +45,14 @@ struct V2Lds {
     off_fr = off_vec + 3 * (6 * nfm + NCMAX + 3);
     off_fr = (off_fr + 1) & ~1u;
     // replicated frame accumulators [value][rep][frame]: as many replicas (<= 8) as the 160 KiB LDS allows
-    const uint32_t fixed = off_fr + np_max * 12 + zd + MISC_DOUBLES + 32 + 64;
+    const uint32_t fixed = off_fr + np_max * SLAB_STRIDE + zd + MISC_DOUBLES + 32 + 64;
     uint32_t r = (LDS_LIMIT_DOUBLES - fixed) / (FRV * nfm);
     nrep = single_replica ? 1u : (r < 1 ? 1 : (r > 8 ? 8 : r));
     off_bt = off_fr + nrep * FRV * nfm;
     off_bt = (off_bt + 1) & ~1u;
-    const bool bt = single_replica && pass_lanes >= 256 && (off_bt + 16 * 256 + np_max * 12 + zd + MISC_DOUBLES + 32 + 64 <= LDS_LIMIT_DOUBLES);
+    const bool bt = single_replica && pass_lanes >= 256 && (off_bt + 16 * 256 + np_max * SLAB_STRIDE + zd + MISC_DOUBLES + 32 + 64 <= LDS_LIMIT_DOUBLES);
     off_slab = off_bt + (bt ? 16 * 256 : 0);
-    off_zd = off_slab + np_max * 12; off_misc = off_zd + zd; total = off_misc + MISC_DOUBLES + 32 + 64;   // misc | point ids (64 u32) | column info (<= 256 u16)
+    off_zd = off_slab + np_max * SLAB_STRIDE; off_misc = off_zd + zd; total = off_misc + MISC_DOUBLES + 32 + 64;   // misc | point ids (64 u32) | column info (<= 256 u16)
   }
   __host__ __device__ bool has_bt() const { return off_slab != off_bt; }
 };
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     if (ps + 1 < ps_end) fetch_pass(ps + 1);
     const uint32_t krows = (3 * np + 3u) & ~3u;   // K of the product, multiple of 4
     STAMP(12);
-    for (uint32_t i = tid; i < 64 * 12; i += 256) slab[i] = 0.0;
+    for (uint32_t i = tid; i < 64 * SLAB_STRIDE; i += 256) slab[i] = 0.0;
     if (mode == 0) { double2* z2 = reinterpret_cast<double2*>(Zd); for (uint32_t i = tid; i < (krows * zs) / 2; i += 256) z2[i] = double2{0.0, 0.0}; }
     STAMP(13);
     lds_barrier();
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < 3; ++j) AR[i][j] = Am[i][0] * R[j] + Am[i][1] * R[3 + j] + Am[i][2] * R[6 + j];
-        double* acc = slab + lp * 12;
+        double* acc = slab + lp * SLAB_STRIDE;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
     if (tid < np) {
       const uint32_t p = fp;
       pidl[tid] = p;
-      double* acc = slab + tid * 12;
+      double* acc = slab + tid * SLAB_STRIDE;
       double U0 = acc[0], U1 = acc[1], U2 = acc[2], U3 = acc[3], U4 = acc[4], U5 = acc[5];
       if (mode == 1) {
         double* ga = d.ptacc + (size_t)p * 36;
@@ -443,7 +446,7 @@ __global__ __launch_bounds__(256) void k_sweep2(Dev d, double radius, int mode) 
         for (uint32_t cc0 = cidx; cc0 < nwc; cc0 += (nwc > 256 ? 256 : nwc * nth)) {
 #pragma unroll 4
           for (uint32_t lp = (nwc > 256 ? 0 : gi); lp < np; lp += (nwc > 256 ? 1 : nth)) {
-            const double* acc = slab + lp * 12;
+            const double* acc = slab + lp * SLAB_STRIDE;
             double* z = Zd + (size_t)(3 * lp) * zs + cc0;
             const double w0 = z[0], w1 = z[zs], w2 = z[2 * zs];
             if (cc0 >= 6 * nf) {

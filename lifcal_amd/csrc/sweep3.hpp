@@ -86,7 +86,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
     colinfo[cI] = (cI < 6 * nf) ? (unsigned short)(((cI / 6) << 8) | (cI % 6)) : (cI < ncol - 1 ? (unsigned short)(0x8000u | (cI - 6 * nf)) : (unsigned short)0xC000u);
 
   // ---- phases both roles run with all 512 threads ----
-  auto zero_slab = [&]() { for (uint32_t i = tid; i < lay.np_max * 12; i += NT) slab[i] = 0.0; };
+  auto zero_slab = [&]() { for (uint32_t i = tid; i < lay.np_max * SLAB_STRIDE; i += NT) slab[i] = 0.0; };
   auto zero_zd = [&](uint32_t krows) { double2* z2 = reinterpret_cast<double2*>(Zd); for (uint32_t i = tid; i < (krows * zs) / 2; i += NT) z2[i] = double2{0.0, 0.0}; };
   // Z = L^-1 W in place (pose + camera columns), camera part of W to HBM first; thread = (column, point phase)
   auto z_phase = [&](uint32_t np) {
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
       for (uint32_t cc0 = cidx; cc0 < nwc; cc0 += (nwc > NT ? NT : nwc * nth)) {
 #pragma unroll 4
         for (uint32_t lp = (nwc > NT ? 0 : gi); lp < np; lp += (nwc > NT ? 1 : nth)) {
-          const double* acc = slab + lp * 12;
+          const double* acc = slab + lp * SLAB_STRIDE;
           double* z = Zd + (size_t)(3 * lp) * zs + cc0;
           const double w0 = z[0], w1 = z[zs], w2 = z[2 * zs];
           if (cc0 >= 6 * nf) {
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
         for (int i = 0; i < 3; ++i)
 #pragma unroll
           for (int j = 0; j < 3; ++j) AR[i][j] = Am[i][0] * R[j] + Am[i][1] * R[3 + j] + Am[i][2] * R[6 + j];
-        double* acc = slab + lp * 12;
+        double* acc = slab + lp * SLAB_STRIDE;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
       if (tid < np) {
         const uint32_t p = fp;
         pidl[tid] = p;
-        double* acc = slab + tid * 12;
+        double* acc = slab + tid * SLAB_STRIDE;
         double U0 = acc[0], U1 = acc[1], U2 = acc[2], U3 = acc[3], U4 = acc[4], U5 = acc[5];
         if (mode == 1) {
           double* ga = d.ptacc + (size_t)p * 36;
