@@ -444,11 +444,20 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
 #pragma unroll
           for (int i = 0; i < 3; ++i) {
             atomicAdd(acc + 6 + i, R[i] * bv[0] + R[3 + i] * bv[1] + R[6 + i] * bv[2]);
-            double* zrow = Zd + (size_t)(3 * lp + i) * zs;
+            // The row stride of Z is even (16-byte rows for the Schur product's double2 reads) and so is the frame stride 6: with
+            // the same column j in every lane an f64 atomic instruction reaches only the EVEN double-banks (4-way conflicts over
+            // 64 lanes).  Lanes of odd points therefore take the six columns rotated by one: instruction jj adds column jj + 1.
+            double* zrow = Zd + (size_t)(3 * lp + i) * zs + 6 * lf;
+            double w6[6];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const double wij = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j]; if (fpose) atomicAdd(zrow + 6 * lf + j, wij); }
+            for (int j = 0; j < 3; ++j) { w6[j] = R[i] * AG[0][j] + R[3 + i] * AG[1][j] + R[6 + i] * AG[2][j]; w6[3 + j] = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j]; }
+            const bool rot = (lp & 1u) != 0;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) { const double wij = R[i] * Am[0][j] + R[3 + i] * Am[1][j] + R[6 + i] * Am[2][j]; if (fpose) atomicAdd(zrow + 6 * lf + 3 + j, wij); }
+            for (int jj = 0; jj < 6; ++jj) {
+              const double wv = rot ? w6[(jj + 1) % 6] : w6[jj];
+              const uint32_t col = rot ? (uint32_t)((jj + 1) % 6) : (uint32_t)jj;
+              if (fpose) atomicAdd(zrow + col, wv);
+            }
           }
         }
       }
@@ -669,10 +678,14 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
           for (int ci = 0; ci < 3; ++ci) { const double v = run_sum(C[ci][j], rm); if (rm.head) atomicAdd(fr_acc + (size_t)(27 + j * 6 + 3 + ci) * frs, v); }
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-          double* zrow = Zd + (size_t)(3 * lp + i) * zs;
+        for (int i = 0; i < 3; ++i) {   // (columns rotated by one for the lanes of odd points: see the evaluators' W rows)
+          double* zrow = Zd + (size_t)(3 * lp + i) * zs + 6 * nf;
+          double wc[NC];
 #pragma unroll
-          for (int j = 0; j < NC; ++j) atomicAdd(zrow + 6 * nf + j, R[i] * C[0][j] + R[3 + i] * C[1][j] + R[6 + i] * C[2][j]);
+          for (int j = 0; j < NC; ++j) wc[j] = R[i] * C[0][j] + R[3 + i] * C[1][j] + R[6 + i] * C[2][j];
+          const bool rot = (lp & 1u) != 0;
+#pragma unroll
+          for (int jj = 0; jj < NC; ++jj) atomicAdd(zrow + (rot ? (uint32_t)((jj + 1) % NC) : (uint32_t)jj), rot ? wc[(jj + 1) % NC] : wc[jj]);
         }
       }
       if (det) { publish(turn, my_turn + 1); my_turn += (uint32_t)WR; }
