@@ -198,9 +198,10 @@ int lifcal_ba_sweep_enqueue(lifcal_ba_handle* h, double radius);
  * profiled sweep, one closes it behind the last.  begin() reserves events for up to max_sweeps sweeps; end() synchronises and averages. */
 typedef struct lifcal_ba_profile {
   uint32_t n_sweeps;
-  double ms_tables;       /* 0 (the table kernel is no longer timed separately: it is part of ms_schur)                 */
-  double ms_accumulate;   /* the dominant kernel(s): k_sweep3 (fused residual + Jacobian + accumulation + point elimination
-                             of the regular points) [+ k_sweep for special points]                                    */
+  double special_points;  /* points worked by the special-point kernels (k_sweep + k_schur: constraints, oversized groups,
+                             camera-only / pose-only arities); their time is part of ms_schur, NOT of ms_accumulate        */
+  double ms_accumulate;   /* the dominant kernel of the regular points by its own dispatch time stamps: k_sweep3 (fused residual +
+                             Jacobian + accumulation + point elimination), or k_front4 start to k_back4 end                */
   double ms_schur;        /* ms_total - ms_accumulate: tables, special points, constraints, exchange, k_finalize, gaps  */
   double ms_total;        /* first kernel of the first sweep to the end of the last one, divided by the sweep count    */
 } lifcal_ba_profile;
@@ -230,6 +231,7 @@ int lifcal_ba_set_fixed_frames(lifcal_ba_handle* h, const uint8_t* fixed /* [n_f
  * collective hooks / communicator of `comm_template` (a handle created on the SAME options, may be NULL at world_size 1) are reused. */
 typedef struct lifcal_ba_window_report {
   uint32_t first_frame, n_frames, n_fixed_frames, n_points, n_obs;
+  uint32_t n_dropped_constraints;   /* distance constraints touching the window whose second point lies outside it (not applied) */
   lifcal_ba_summary summary;
 } lifcal_ba_window_report;
 int lifcal_ba_solve_windowed(const lifcal_ba_problem* p, const lifcal_ba_options* o, uint32_t window_frames, uint32_t overlap_frames,

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "liblifcal_ba.so")
+LIB_PATH = os.environ.get("LIFCAL_BA_LIB") or os.path.join(_HERE, "csrc", "liblifcal_ba.so")   # (LIFCAL_BA_LIB: a development build, e.g. make dev / make stamps)
 
 dptr = C.POINTER(C.c_double)
 uptr = C.POINTER(C.c_uint32)
@@ -69,13 +69,13 @@ class Info(C.Structure):
 
 
 class Profile(C.Structure):
-    _fields_ = [("n_sweeps", C.c_uint32), ("ms_tables", C.c_double), ("ms_accumulate", C.c_double),
+    _fields_ = [("n_sweeps", C.c_uint32), ("special_points", C.c_double), ("ms_accumulate", C.c_double),
                 ("ms_schur", C.c_double), ("ms_total", C.c_double)]
 
 
 class WindowReport(C.Structure):   # lifcal_ba_window_report
     _fields_ = [("first_frame", C.c_uint32), ("n_frames", C.c_uint32), ("n_fixed_frames", C.c_uint32), ("n_points", C.c_uint32), ("n_obs", C.c_uint32),
-                ("summary", Summary)]
+                ("n_dropped_constraints", C.c_uint32), ("summary", Summary)]
 
 
 class Partition(C.Structure):      # lifcal_ba_partition

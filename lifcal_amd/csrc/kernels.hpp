@@ -28,6 +28,7 @@
 
 namespace lifcal {
 
+constexpr uint32_t DET_NF_MAX = 20;   // widest frame window of a block (Plan::NF_MAX; lifcal_ba.hip checks the two against each other)
 constexpr int SCAL_COST = 0, SCAL_BAD_U = 1, SCAL_GMAX0 = 2, SCAL_N = 2 + 64;
 // host-visible scalars of one LM step
 constexpr int ST_GTD = 0, ST_DDD = 1, ST_STEP2 = 2, ST_X2 = 3, ST_CAND_COST = 4, ST_CHOL_FAIL = 5, ST_GMAX_RED = 6, ST_DIR = 7, ST_N = 8;
@@ -67,6 +68,9 @@ struct Dev {
   uint32_t n_blocks, v2_nfmax, n_special;
   const uint32_t *blk_pass0, *blk_flo, *blk_nf, *pass_pt0, *pass_np, *pass_gid0, *pass_ng, *v2_points, *v2_ptinfo, *v2_slot, *v2_tile_row0, *v2_lens, *v2f_pt, *v2_passpt, *v2_gidx;
   const double *v2_u, *v2_v;
+  // k_front4 / k_back4 (sweep4.hpp): front workgroup -> block and pass range; block -> range of v2_points
+  uint32_t n_fwg;
+  const uint32_t *fwg_blk, *fwg_pass0, *blk_pt0;
   const float *v2_du, *v2_dv;    // options.precision = 1: observation relative to its micro-lens centre (u - mcx, v - mcy), fp32
   float* ltf;                    // options.precision = 1: fp32 lens table of the CURRENT point (see lens_row_to_float)
   double* ltw;                   // ... and w = (a) c_u of every lens in fp64 (2 per lens): the one fp64 operand of the fp32 evaluation
@@ -393,6 +397,7 @@ LIFCAL_DEV double finalize_column(const Dev& d, uint32_t t, double radius) {
 }  // namespace lifcal
 #include "sweep2.hpp"   // k_sweep2: the LDS-window fused sweep (regular points)
 #include "sweep3.hpp"   // k_sweep3: the same with a wave-specialised observation loop (512 threads)
+#include "sweep4.hpp"   // k_front4 + k_back4: the sweep cut in two kernels built for occupancy (default)
 namespace lifcal {
 
 // ---------------------------------------------------------------------------------------------
@@ -684,7 +689,7 @@ __global__ void k_det_reduce(Dev d, int mode) {
     while (lo < hi) { const uint32_t m = (lo + hi) >> 1; if (d.blk_flo[m] <= fa) lo = m + 1; else hi = m; }
     b1 = lo;                                        // candidates end here (exclusive)
     b0 = b1;
-    while (b0 > 0 && d.blk_flo[b0 - 1] + 20u > fb) --b0;   // Plan::NF_MAX = 20
+    while (b0 > 0 && d.blk_flo[b0 - 1] + DET_NF_MAX > fb) --b0;
   };
   double sum = 0.0;
   double* dst = nullptr;

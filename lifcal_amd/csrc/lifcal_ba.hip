@@ -28,6 +28,9 @@
 
 using namespace lifcal;
 
+static_assert(lifcal::DET_NF_MAX == lifcal::Plan::NF_MAX, "k_det_reduce searches the covering blocks of a frame inside Plan::NF_MAX frames");
+static_assert(lifcal::Plan::PASS_GROUPS == 256, "k_det_reduce / k_det_reduce_all read the window layout of 256-lane passes (V2Lds(nf, true, 256))");
+
 #ifndef LIFCAL_DEFAULT_SWEEP_WAVES
 #define LIFCAL_DEFAULT_SWEEP_WAVES 4
 #endif
@@ -87,6 +90,8 @@ struct lifcal_ba_handle {
   size_t v2_lds_bytes = 0;
   bool use_sweep3 = true;        // wave-specialised LDS-window kernel (LIFCAL_SWEEP_KERNEL=2 selects k_sweep2)
   int sweep_waves = 4;           // k_sweep3: waves per role, 4 (512 threads, 256-lane passes) or 2 (256 threads, 128-lane passes, two workgroups per CU)
+  bool use_sweep4 = false;       // k_front4 + k_back4 (sweep4.hpp): LIFCAL_SWEEP_KERNEL=4, fp64 and non-deterministic problems only
+  size_t f4_lds = 0, b4_lds = 0; int b4_tpt = 1;
   TileSet ts1{}, ts2{};   // v1 tiles, v2 tiles (flat view)
   double* partial = nullptr;     // 4 doubles + 1 cand cost (all-reduced)
   double* hdiag_tmp = nullptr;
@@ -164,6 +169,11 @@ int exchange_reduced(lifcal_ba_handle* h) {
   return 0;
 }
 
+#ifdef LIFCAL_ONLY_FULL_CFG
+// development builds (make dev): only the <2 radial, tangential, mlCenterAdj> instantiations, a fraction of the compile time
+#define DISPATCH_CFG(h, CALL) do { if ((h)->plan.n_radial == 2 && (h)->plan.tangential && (h)->plan.adj) { CALL(2, true, true); } else { g_last_error = "development build: configuration not compiled in"; return LIFCAL_BA_ERR_INVALID_ARG; } } while (0)
+#define DISPATCH_LENS(h, CALL) do { if ((h)->plan.n_radial == 2 && (h)->plan.tangential) { CALL(2, true); } else { g_last_error = "development build: configuration not compiled in"; return LIFCAL_BA_ERR_INVALID_ARG; } } while (0)
+#else
 #define DISPATCH_CFG(h, CALL)                                                       \
   do {                                                                              \
     const int nr_ = (h)->plan.n_radial; const bool tn_ = (h)->plan.tangential, aj_ = (h)->plan.adj; \
@@ -188,6 +198,7 @@ int exchange_reduced(lifcal_ba_handle* h) {
     else if (nr_ == 1 && !tn_) { CALL(1, false); } else if (nr_ == 1) { CALL(1, true); } \
     else if (!tn_) { CALL(2, false); } else { CALL(2, true); }                      \
   } while (0)
+#endif
 
 uint32_t sweep_grid(const lifcal_ba_handle* h) {
   const uint32_t tiles = h->plan.n_tiles;
@@ -217,7 +228,17 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
   // kernel's dispatch packet itself) — event records around it are separate barrier packets, ~2 us of idle queue each, four per sweep
   const bool prof = mode == 0 && h->prof_active();
   hipEvent_t ev_a = prof ? h->prof_ev(1) : nullptr, ev_b = prof ? h->prof_ev(2) : nullptr;
-  if (d.n_blocks) {   // regular points: LDS-window kernel, one workgroup per block
+  if (d.n_blocks && h->use_sweep4) {   // regular points: observations -> blocks (k_front4), then the point elimination per block (k_back4)
+#define CALL_FRONT4(NR, TAN, ADJ) hipExtLaunchKernelGGL((k_front4<NR, TAN, ADJ>), dim3(d.n_fwg), dim3(F4_THREADS), h->f4_lds, h->stream, ev_a, mode == 0 ? nullptr : ev_b, 0, d, mode)
+    DISPATCH_CFG(h, CALL_FRONT4);
+#undef CALL_FRONT4
+    if (mode == 0) {
+#define CALL_BACK4(NCV) do { if (h->b4_tpt == 1) hipExtLaunchKernelGGL((k_back4<NCV, 1>), dim3(d.n_blocks), dim3(B4_THREADS), h->b4_lds, h->stream, nullptr, ev_b, 0, d, radius); \
+                             else hipExtLaunchKernelGGL((k_back4<NCV, 2>), dim3(d.n_blocks), dim3(B4_THREADS), h->b4_lds, h->stream, nullptr, ev_b, 0, d, radius); } while (0)
+      switch (d.nc) { case 5: CALL_BACK4(5); break; case 6: CALL_BACK4(6); break; case 7: CALL_BACK4(7); break; case 8: CALL_BACK4(8); break; default: CALL_BACK4(9); break; }
+#undef CALL_BACK4
+    }
+  } else if (d.n_blocks) {   // regular points: LDS-window kernel, one workgroup per block
     hipEvent_t ev_stop = d.deterministic ? nullptr : ev_b;   // (deterministic: the slab reduction below belongs to the dominant work)
 #define LAUNCH_DOM(KERNEL, THREADS) hipExtLaunchKernelGGL(KERNEL, dim3(d.n_blocks), dim3(THREADS), h->v2_lds_bytes, h->stream, ev_a, ev_stop, 0, d, radius, mode)
 #define CALL_SWEEP2(NR, TAN, ADJ) LAUNCH_DOM((k_sweep2<NR, TAN, ADJ>), 256)
@@ -406,13 +427,30 @@ int eval_trial(lifcal_ba_handle* h, double t, double radius, LsSample* smp) {
     hipLaunchKernelGGL(k_dirderiv, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, h->ls_buf + 2);
     if (hipGetLastError() != hipSuccess) rc = LIFCAL_BA_ERR_HIP;
   }
+  // options.precision = 1: the sweep's cost is that of the fp32 residuals, while phi(0) = x_cost and the candidate costs of the LM
+  // loop come from the fp64 value kernel — near convergence the offset between the two arithmetics (~1e-7 relative) is far larger
+  // than the Armijo margin, so the trial value is taken from the SAME fp64 kernel on the trial point's tables (ls_buf[3])
+  const bool value64 = h->opt.precision == 1;
+  if (!rc && value64) {
+    const double* pts_eval = d.pts;   // (swapped: the trial point)
+    for (const TileSet* ts : {&h->ts1, &h->ts2}) {
+      if (!ts->n_tiles) continue;
+      const uint32_t grid = std::max(1u, std::min((ts->n_tiles + 3) / 4, 1024u));
+#define CALL_COSTT(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)d.camc, (const double*)d.ft, (const double*)d.lt, pts_eval, h->ls_buf + 3)
+      DISPATCH_CFG(h, CALL_COSTT);
+#undef CALL_COSTT
+    }
+    if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->ls_buf + 3);
+    if (hipGetLastError() != hipSuccess) rc = LIFCAL_BA_ERR_HIP;
+  }
   swap_all();
   if (rc) return rc;
-  if (int rc2 = do_allreduce(h, h->ls_buf, 3)) return rc2;
+  if (int rc2 = do_allreduce(h, h->ls_buf, value64 ? 4 : 3)) return rc2;
   double hb[8], cost;
   HIP_TRY(hipMemcpyAsync(hb, h->ls_buf, sizeof(hb), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipMemcpyAsync(&cost, d.scal + SCAL_COST, sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (value64) cost = hb[3];
   smp->x = t; smp->value = cost; smp->value_valid = std::isfinite(cost);
   smp->gradient = hb[2]; smp->gradient_valid = smp->value_valid && std::isfinite(smp->gradient);
   return 0;
@@ -565,6 +603,19 @@ int lifcal_init_plenoptic(const lifcal_init_problem* p, int32_t device, lifcal_i
   return 0;
 }
 
+// the sweep implementation for regular points (LIFCAL_SWEEP_KERNEL): 3 = k_sweep3 (default), 2 = k_sweep2, 4 = k_front4 + k_back4
+// (sweep4.hpp: the two-kernel, pipelined-evaluator design of round 3 — parity green, measured slower than k_sweep3: DESIGN.md 4.5)
+static int sweep_kernel_from_env() {
+  const char* e = getenv("LIFCAL_SWEEP_KERNEL");
+  const int k = e ? atoi(e) : 3;
+  return (k == 2 || k == 4) ? k : 3;
+}
+// the planner's layout for a kernel choice: lanes per pass and number of blocks
+static void sweep_layout(int kernel, int waves, uint32_t* pass_lanes, uint32_t* blocks) {
+  if (kernel == 4) { *pass_lanes = 64u; *blocks = 256u; }
+  else { *pass_lanes = waves == 2 ? 128u : 256u; *blocks = waves == 2 ? 512u : 256u; }
+}
+
 // k_sweep3's waves per role: LIFCAL_SWEEP_WAVES = 2 | 4 (k_sweep2 always works on 256-lane passes)
 static int sweep_waves_from_env(bool sweep3) {
   if (!sweep3) return 4;
@@ -584,9 +635,11 @@ int lifcal_ba_plan(const lifcal_ba_problem* p, int32_t rank, int32_t world_size,
                    uint32_t* obs_order, uint32_t* point_owner) {
   Plan pl;
   // the same layout lifcal_ba_create builds by default (lanes in frame order for the wave-specialised sweep kernel)
-  const bool frame_order = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
-  const int waves = sweep_waves_from_env(frame_order);
-  if (int rc = build_plan(p, rank, world_size, &pl, true, waves == 2 ? 512u : 256u, UINT32_MAX, frame_order, waves == 2 ? 128u : 256u)) return rc;
+  const int kernel = sweep_kernel_from_env();
+  const bool frame_order = kernel != 2;
+  const int waves = sweep_waves_from_env(kernel == 3);
+  uint32_t plan_lanes, plan_blocks; sweep_layout(kernel, waves, &plan_lanes, &plan_blocks);
+  if (int rc = build_plan(p, rank, world_size, &pl, true, plan_blocks, UINT32_MAX, frame_order, plan_lanes)) return rc;
   if (info) {
     info->n_groups = pl.n_pairs; info->n_tiles = pl.n_tiles; info->n_lenses = pl.n_lenses; info->n_promoted = pl.Q;
     info->n_reduced = pl.n_red_canon; info->max_group_obs = pl.max_group_obs; info->n_chunks = pl.n_blocks; info->max_window_frames = pl.bw + 1;
@@ -611,9 +664,11 @@ int lifcal_ba_partition_points(const lifcal_ba_problem* index_only, lifcal_ba_pa
 int lifcal_ba_plan_shard(const lifcal_ba_problem* local, const lifcal_ba_partition* part, int32_t rank, lifcal_ba_plan_info* info) {
   if (!part || !info) return LIFCAL_BA_ERR_INVALID_ARG;
   Plan pl;
-  const bool frame_order = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
-  const int waves = sweep_waves_from_env(frame_order);
-  if (int rc = build_plan(local, rank, (int)part->world_size, &pl, true, waves == 2 ? 512u : 256u, UINT32_MAX, frame_order, waves == 2 ? 128u : 256u, false, part)) return rc;
+  const int kernel = sweep_kernel_from_env();
+  const bool frame_order = kernel != 2;
+  const int waves = sweep_waves_from_env(kernel == 3);
+  uint32_t plan_lanes, plan_blocks; sweep_layout(kernel, waves, &plan_lanes, &plan_blocks);
+  if (int rc = build_plan(local, rank, (int)part->world_size, &pl, true, plan_blocks, UINT32_MAX, frame_order, plan_lanes, false, part)) return rc;
   info->n_groups = pl.n_pairs; info->n_lenses = pl.n_lenses; info->n_promoted = pl.Q;
   info->n_reduced = pl.n_red_canon; info->max_group_obs = pl.max_group_obs; info->n_chunks = pl.n_blocks; info->max_window_frames = pl.bw + 1;
   info->n_tiles = pl.n_tiles + pl.pass_tiles() * pl.n_passes;
@@ -637,8 +692,12 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
   // LIFCAL_V2_BLOCKS sets the number of workgroups the LDS-window sweep is cut into (default: one per CU)
   const bool enable_v2 = getenv("LIFCAL_DISABLE_V2") == nullptr;
   // the wave-specialised kernel wants the lanes of a pass sorted by frame, k_sweep2 (LIFCAL_SWEEP_KERNEL=2) by point
-  h->use_sweep3 = !(getenv("LIFCAL_SWEEP_KERNEL") && atoi(getenv("LIFCAL_SWEEP_KERNEL")) == 2);
-  h->sweep_waves = sweep_waves_from_env(h->use_sweep3);
+  int kernel = sweep_kernel_from_env();
+  // ordered reductions and the fp32 evaluation exist in k_sweep3 only
+  if (kernel == 4 && (opt.deterministic == 1 || opt.precision == 1)) kernel = 3;
+  h->use_sweep3 = kernel != 2;   // (frame-ordered lanes: k_sweep3 and k_front4)
+  h->use_sweep4 = kernel == 4;
+  h->sweep_waves = sweep_waves_from_env(kernel == 3);
   if (opt.deterministic == 1) {
     if (!h->use_sweep3) { g_last_error = "options.deterministic = 1 needs k_sweep3 (unset LIFCAL_SWEEP_KERNEL)"; delete h; return LIFCAL_BA_ERR_INVALID_ARG; }
     h->sweep_waves = 4;
@@ -648,14 +707,29 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
     if (!h->use_sweep3) { g_last_error = "options.precision = 1 needs k_sweep3 (unset LIFCAL_SWEEP_KERNEL)"; delete h; return LIFCAL_BA_ERR_INVALID_ARG; }
     h->sweep_waves = 4;
   }
-  const uint32_t v2_blocks = getenv("LIFCAL_V2_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("LIFCAL_V2_BLOCKS"))) : (h->sweep_waves == 2 ? 512u : 256u);
+  uint32_t plan_lanes, plan_blocks; sweep_layout(kernel, h->sweep_waves, &plan_lanes, &plan_blocks);
+  const uint32_t v2_blocks = getenv("LIFCAL_V2_BLOCKS") ? (uint32_t)std::max(1, atoi(getenv("LIFCAL_V2_BLOCKS"))) : plan_blocks;
   // LIFCAL_GROUP_SPLIT: observations per lane above which a (point, frame) group is cut into several lanes
   // (0 = never; default: chosen per block by the planner's cost model)
   const uint32_t split_obs = getenv("LIFCAL_GROUP_SPLIT") ? (uint32_t)std::max(0, atoi(getenv("LIFCAL_GROUP_SPLIT"))) : UINT32_MAX;
   h->trace = getenv("LIFCAL_TRACE") != nullptr;
   PlanClock cclk;
-  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs, h->use_sweep3, h->sweep_waves == 2 ? 128u : 256u, opt.precision == 1, part);
+  int rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, v2_blocks, split_obs, h->use_sweep3, plan_lanes, opt.precision == 1, part);
   if (rc) { delete h; return rc; }
+  if (h->use_sweep4) {
+    // k_back4 keeps at most two 4x4 tiles of the window per thread of a 256-thread group: wider frame windows take k_sweep3
+    uint32_t max_ntri = 0;
+    for (uint32_t b = 0; b < h->plan.n_blocks; ++b) max_ntri = std::max(max_ntri, V4Back::ntri_of(h->plan.blk_nf[b], (uint32_t)h->plan.nc));
+    if (max_ntri > 512) {
+      h->use_sweep4 = false; h->sweep_waves = 4;
+      sweep_layout(3, 4, &plan_lanes, &plan_blocks);
+      h->plan = Plan();
+      rc = build_plan(p, opt.rank, opt.world_size, &h->plan, enable_v2, getenv("LIFCAL_V2_BLOCKS") ? v2_blocks : plan_blocks, split_obs, true, plan_lanes, false, part);
+      if (rc) { delete h; return rc; }
+    } else {
+      h->b4_tpt = max_ntri > 256 ? 2 : 1;
+    }
+  }
   cclk.lap("create: plan");
   h->prob = *p;
   int ndev = 0;
@@ -718,19 +792,59 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
   for (uint32_t b = 0; b < L.n_blocks; ++b) {
     const uint32_t ncolp = ((6 * L.blk_nf[b] + (uint32_t)L.nc + 1) + 15u) & ~15u;
     for (uint32_t ps = L.blk_pass0[b]; ps < L.blk_pass0[b + 1]; ++ps)
-      if ((size_t)((3 * L.pass_np[ps] + 7u) & ~7u) * (ncolp + 2) > L.zd_doubles() || L.pass_ng[ps] > L.pass_lanes || L.pass_np[ps] > L.np_max()) {
+      if ((!h->use_sweep4 && (size_t)((3 * L.pass_np[ps] + 7u) & ~7u) * (ncolp + 2) > L.zd_doubles()) || L.pass_ng[ps] > L.pass_lanes || L.pass_np[ps] > L.np_max()) {
         g_last_error = "internal: a planned pass does not fit the LDS window";
         return fail(LIFCAL_BA_ERR_INVALID_ARG);
       }
   }
   h->v2_lds_bytes = (size_t)V2Lds(d.v2_nfmax, h->use_sweep3, L.pass_lanes).total * sizeof(double);
+  if (h->use_sweep4) {
+    h->f4_lds = (size_t)V4Front(d.v2_nfmax).total * sizeof(double);
+    h->b4_lds = (size_t)V4Back(d.v2_nfmax).total * sizeof(double);
+  }
   d.deterministic = opt.deterministic == 1 ? 1u : 0u;
   if (d.deterministic) {
     d.det_stride = (V2Lds(d.v2_nfmax, true, 256).off_fr + 3u + 1u) & ~1u;
     A(d.det_slab, (size_t)std::max(1u, d.n_blocks) * d.det_stride);
     A(d.det_slots, 4 * (size_t)std::max<uint32_t>(1024u, (std::max(4 * d.n_owned, d.Q) + 255u) / 256u));
   }
-  if (d.n_blocks) {
+  if (d.n_blocks && h->use_sweep4) {
+    // k_front4: as many workgroups as the chip holds at once (each walks a contiguous share of one block's tiles)
+    int per_cu = 0;
+#define SET_F4(NR, TAN, ADJ) do { if (hipFuncSetAttribute((const void*)k_front4<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->f4_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_front4<NR, TAN, ADJ>, (int)F4_THREADS, h->f4_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); } while (0)
+    DISPATCH_CFG(h, SET_F4);
+#undef SET_F4
+#define SET_B4(NCV) do { if (hipFuncSetAttribute((const void*)k_back4<NCV, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->b4_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
+    if (hipFuncSetAttribute((const void*)k_back4<NCV, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->b4_lds) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); } while (0)
+    switch (d.nc) { case 5: SET_B4(5); break; case 6: SET_B4(6); break; case 7: SET_B4(7); break; case 8: SET_B4(8); break; default: SET_B4(9); break; }
+#undef SET_B4
+    per_cu = std::max(1, std::min(per_cu, 5));
+    if (const char* e = getenv("LIFCAL_F4_PER_CU")) per_cu = std::max(1, atoi(e));
+    const uint32_t capacity = (uint32_t)per_cu * (uint32_t)std::max(1, prop.multiProcessorCount);
+    const uint32_t parts = std::max(1u, capacity / std::max(1u, d.n_blocks));
+    std::vector<uint32_t> fwg_blk, fwg_pass0, blk_pt0(L.n_blocks + 1, 0);
+    for (uint32_t b = 0; b < L.n_blocks; ++b) {
+      const uint32_t p0 = L.blk_pass0[b], p1 = L.blk_pass0[b + 1];
+      blk_pt0[b] = p0 < L.n_passes ? L.pass_pt0[p0] : (uint32_t)L.v2_points.size();
+      // a tile costs its observation steps plus a fixed share (emission, gather): cut the block's tiles into `parts` equal runs
+      auto tile_cost = [&](uint32_t ps) { return (uint64_t)(L.v2_tile_row0[ps + 1] - L.v2_tile_row0[ps]) + 3u; };
+      uint64_t total = 0;
+      for (uint32_t ps = p0; ps < p1; ++ps) total += tile_cost(ps);
+      const uint32_t np = std::min(parts, std::max(1u, p1 - p0));
+      uint64_t acc = 0; uint32_t next = 0;
+      for (uint32_t ps = p0; ps < p1; ++ps) {
+        if (next < np && acc * np >= (uint64_t)next * total) { fwg_blk.push_back(b); fwg_pass0.push_back(ps); ++next; }
+        acc += tile_cost(ps);
+      }
+    }
+    blk_pt0[L.n_blocks] = (uint32_t)L.v2_points.size();
+    fwg_pass0.push_back(L.n_passes);
+    d.n_fwg = (uint32_t)fwg_blk.size();
+    if (cclk.on) std::fprintf(stderr, "[create] k_front4: %d workgroups per CU (occupancy API), %u workgroups over %u blocks, LDS %zu B; k_back4: LDS %zu B, %d tile(s) per thread\n",
+                              per_cu, d.n_fwg, d.n_blocks, h->f4_lds, h->b4_lds, h->b4_tpt);
+    { uint32_t* t; U(t, fwg_blk); d.fwg_blk = t; U(t, fwg_pass0); d.fwg_pass0 = t; U(t, blk_pt0); d.blk_pt0 = t; }
+  } else if (d.n_blocks) {
 #define SET_LDS(NR, TAN, ADJ) do { if (hipFuncSetAttribute((const void*)k_sweep2<NR, TAN, ADJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
     if (hipFuncSetAttribute((const void*)k_sweep3<NR, TAN, ADJ, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
     if (hipFuncSetAttribute((const void*)k_sweep3<NR, TAN, ADJ, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->v2_lds_bytes) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP); \
@@ -777,7 +891,7 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
       h->xch_ok = true;
     }
   }
-  A(d.dbg, (size_t)std::max(1u, d.n_blocks) * 32);
+  A(d.dbg, std::max((size_t)std::max(1u, d.n_blocks) * 32, (size_t)d.n_fwg * 64));
   A(d.dP, 3 * (size_t)d.P); A(h->ls_buf, 8); A(h->dirmax_buf, 65);
   d.step = d.scal + SCAL_N; h->partial = d.step + ST_N;   // (behind the all-reduced block, not part of it)
   A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->stats_slots, 4 + 2 * 64); A(h->pts_gather, 3 * (size_t)d.P);
@@ -846,6 +960,8 @@ int lifcal_ba_set_fixed_frames(lifcal_ba_handle* h, const uint8_t* fixed) {
   HIP_TRY(hipSetDevice(h->opt.device));
   std::vector<uint8_t> live(h->plan.frame_used);
   if (fixed) for (uint32_t f = 0; f < h->d.F; ++f) if (fixed[f]) live[f] = 0;
+  // a solve boundary: sweeps still queued on the (non-blocking) stream read the old mask to the end before it changes
+  HIP_TRY(hipStreamSynchronize(h->stream));
   if (!live.empty()) HIP_TRY(hipMemcpy(h->frame_live_dev, live.data(), live.size(), hipMemcpyHostToDevice));
   h->sigma_valid = false;   // the Jacobi scaling is fixed at the first sweep of a solve: a new column set starts a new solve
   return 0;
@@ -888,8 +1004,13 @@ int lifcal_ba_comm_init_rccl(lifcal_ba_handle* h, const void* unique_id128) {
 // diagnostic build only: copies the per-block phase cycle counters of the last k_sweep2 launch (32 per block: 16 of thread 0, 16 of thread 256)
 extern "C" int lifcal_ba_debug_stamps(lifcal_ba_handle* h, unsigned long long* out, uint32_t max_blocks) {
   if (!h || !out) return LIFCAL_BA_ERR_INVALID_ARG;
-  const uint32_t n = std::min(max_blocks, h->d.n_blocks);
   HIP_TRY(hipStreamSynchronize(h->stream));
+  if (h->use_sweep4) {   // k_front4: 64 counters per front workgroup (16 per role)
+    const uint32_t n = std::min(max_blocks / 2, h->d.n_fwg);
+    HIP_TRY(hipMemcpy(out, h->d.dbg, (size_t)n * 64 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return (int)n;
+  }
+  const uint32_t n = std::min(max_blocks, h->d.n_blocks);
   HIP_TRY(hipMemcpy(out, h->d.dbg, (size_t)n * 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   return (int)n;
 }
@@ -935,7 +1056,7 @@ int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out) {
     float t = 0;   // first kernel of the first sweep -> end of the last sweep (includes the gaps between sweeps)
     HIP_TRY(hipEventElapsedTime(&t, h->prof_events[0], h->prof_events[(size_t)(n - 1) * 6 + 5]));
     out->ms_total = t / n; out->ms_accumulate /= n;
-    out->ms_tables = 0.0;                                   // (not separated any more: it would take a barrier packet per sweep)
+    out->special_points = (double)h->d.n_special;           // (their kernels run outside the dominant kernel's time stamps)
     out->ms_schur = out->ms_total - out->ms_accumulate;     // everything outside the dominant kernel: tables, finalize, special points, exchange, launch gaps
   }
   out->n_sweeps = n;

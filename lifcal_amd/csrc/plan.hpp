@@ -88,10 +88,10 @@ struct Plan {
   // block  = one workgroup: contiguous range of points whose frames fit a window of <= NF_MAX frames
   // pass   = <= pass_lanes (256 or 128) lanes / <= pass_lanes / 4 points of a block, in tiles of 64 lanes
   static constexpr uint32_t NF_MAX = 20, NP_MAX = 64, PASS_GROUPS = 256, ZD_DOUBLES = 8192;
-  uint32_t pass_lanes = PASS_GROUPS;   // lanes per pass of this plan: 256 (four tiles) or 128 (two tiles, half the Z matrix: k_sweep3 with two waves per role)
+  uint32_t pass_lanes = PASS_GROUPS;   // lanes per pass of this plan: 256 (four tiles), 128 (two tiles, half the Z matrix: k_sweep3 with two waves per role) or 64 (one tile of whole points: k_front4 + k_back4, sweep4.hpp)
   uint32_t pass_tiles() const { return pass_lanes / 64; }
   uint32_t zd_doubles() const { return pass_lanes >= 256 ? ZD_DOUBLES : ZD_DOUBLES / 2; }
-  uint32_t np_max() const { return pass_lanes / 4; }
+  uint32_t np_max() const { return pass_lanes == 64 ? 64u : pass_lanes / 4; }   // (64-lane passes: no Z matrix per pass, a tile may hold 64 one-lane points)
   uint32_t n_blocks = 0, n_passes = 0, max_block_nf = 0;
   std::vector<uint8_t> pt_special;     // P: the point takes the v1 (global-atomic) kernels
   std::vector<uint32_t> rk_flo, rk_nfr;   // per rank: first frame and number of frames its points observe (identical on every rank)
@@ -179,7 +179,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   clk.lap("validate");
   if (world < 1 || rank < 0 || rank >= world) return LIFCAL_BA_ERR_INVALID_ARG;
   Plan& L = *pl;
-  if (pass_lanes != 128 && pass_lanes != 256) return LIFCAL_BA_ERR_INVALID_ARG;
+  if (pass_lanes != 64 && pass_lanes != 128 && pass_lanes != 256) return LIFCAL_BA_ERR_INVALID_ARG;
   L.pass_lanes = pass_lanes;
   const uint32_t PL = L.pass_lanes, PT = L.pass_tiles();
   L.F = p->n_frames; L.P = p->n_points; L.N = p->n_obs; L.M = p->n_constraints;
@@ -390,6 +390,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     blk_begin.push_back(reg.size());
   }
   auto block_np_cap = [&](size_t b) {
+    if (PL == 64) return L.np_max();   // k_front4 keeps no Z matrix per pass (k_back4 chunks the block's points itself)
     // the dense Z matrix of a pass (3 np rows x padded window columns) must fit its LDS budget
     const uint32_t ncolp = ((6 * L.blk_nf[b] + (uint32_t)L.nc + 1) + 15u) & ~15u;
     return std::max(1u, std::min<uint32_t>(L.np_max(), ((L.zd_doubles() / (ncolp + 2)) & ~7u) / 3));
@@ -407,7 +408,8 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     std::vector<uint32_t> split_of(L.P, 0);   // 0 = leave the point's groups whole
     auto parts_of = [](uint32_t n, uint32_t T) { return T ? (n + T - 1) / T : 1u; };
     // cycles per observation step of a pass, per pass, per lane (LIFCAL_PLAN_COST="step,pass,lane" overrides: tuning aid)
-    double C_STEP = 4700.0, C_PASS = (PL >= 256 ? 21500.0 : 13000.0), C_LANE = 65.0;
+    // (64-lane passes, k_front4: a tile costs its observation steps plus the emission / gather of one wave; lanes are nearly free)
+    double C_STEP = PL == 64 ? 1000.0 : 4700.0, C_PASS = (PL >= 256 ? 21500.0 : (PL == 128 ? 13000.0 : 3000.0)), C_LANE = PL == 64 ? 10.0 : 65.0;
     if (const char* e = getenv("LIFCAL_PLAN_COST")) { double a, b2, c2; if (sscanf(e, "%lf,%lf,%lf", &a, &b2, &c2) == 3) { C_STEP = a; C_PASS = b2; C_LANE = c2; } }
     // blocks are independent (each writes split_of / pass_break of its own points only)
     plan_parallel_for(blk_begin.empty() ? 0u : (uint32_t)(blk_begin.size() - 1), 4, [&](uint32_t b) {
@@ -441,7 +443,7 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
           uint32_t ng = 0, st = 0; size_t e = i;
           while (e < n && e - i < np_cap && ng + lanes[e * nT + t] <= PL) { ng += lanes[e * nT + t]; st = std::max(st, steps[e * nT + t]); ++e; }
           if (e == i) continue;                                                  // a single point too wide for this split size
-          if (Ts[t] != 0 && lanes[i * nT + t] > PL / 4 && nT > 1) continue;   // keep several points per pass
+          if (Ts[t] != 0 && lanes[i * nT + t] > (PL == 64 ? PL / 2 : PL / 4) && nT > 1) continue;   // keep several points per pass
           const double c = C_STEP * st + C_PASS + C_LANE * ng + cost[e];
           if (c < best) { best = c; pick[i] = (uint32_t)t; nxt[i] = (uint32_t)e; }
         }

@@ -7,8 +7,23 @@
 #include <algorithm>
 #include <vector>
 
-extern "C" int lifcal_ba_solve_windowed(const lifcal_ba_problem* p, const lifcal_ba_options* o, uint32_t window_frames, uint32_t overlap_frames,
-                                        lifcal_ba_handle* comm_template, lifcal_ba_window_report* per_window, uint32_t* n_windows) {
+// every rank leaves a window with the same verdict: a rank-local failure (create, fixed frames, solve) travels as one all-reduced
+// double through the borrowed collectives BEFORE any rank enters the next stage's collectives (a rank that returned alone left the
+// others waiting in the window's all-reduces)
+static int windowed_agree(lifcal_ba_handle* comm_template, const lifcal_ba_options& opt, double* dev_flag, int rc) {
+  if (opt.world_size <= 1 || !comm_template) return rc;
+  const double mine = rc ? 1.0 : 0.0;
+  double all = 1.0;
+  if (hipMemcpy(dev_flag, &mine, sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return LIFCAL_BA_ERR_HIP;
+  if (int rc2 = do_allreduce(comm_template, dev_flag, 1)) return rc2;
+  if (hipStreamSynchronize(comm_template->stream) != hipSuccess || hipMemcpy(&all, dev_flag, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return LIFCAL_BA_ERR_HIP;
+  if (rc) return rc;
+  if (all != 0.0) { g_last_error = "lifcal_ba_solve_windowed: another rank failed in this window"; return LIFCAL_BA_ERR_COMM; }
+  return 0;
+}
+
+static int solve_windowed_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, uint32_t window_frames, uint32_t overlap_frames,
+                               lifcal_ba_handle* comm_template, lifcal_ba_window_report* per_window, uint32_t* n_windows, double* dev_flag) {
   if (!p || !n_windows || window_frames == 0 || overlap_frames >= window_frames) return LIFCAL_BA_ERR_INVALID_ARG;
   if (int rc = lifcal::plan_validate(p)) return rc;
   lifcal_ba_options opt; if (o) opt = *o; else lifcal_ba_default_options(&opt);
@@ -42,9 +57,13 @@ extern "C" int lifcal_ba_solve_windowed(const lifcal_ba_problem* p, const lifcal
     for (size_t j = 0; j < pts_ids.size(); ++j) for (int c = 0; c < 3; ++c) pts[3 * j + c] = p->pts[3 * (size_t)pts_ids[j] + c];
     // distance constraints whose two points both belong to the window
     std::vector<uint32_t> ci, cj; std::vector<double> cd, cs;
+    uint32_t dropped = 0;   // constraints with exactly one point in the window cannot be applied there: reported, not silent
     if (p->use_constraints && p->n_constraints && p->c_i && p->c_j)
-      for (uint32_t c = 0; c < p->n_constraints; ++c)
-        if (local_of[p->c_i[c]] >= 0 && local_of[p->c_j[c]] >= 0) { ci.push_back((uint32_t)local_of[p->c_i[c]]); cj.push_back((uint32_t)local_of[p->c_j[c]]); cd.push_back(p->c_dist[c]); cs.push_back(p->c_sigma[c]); }
+      for (uint32_t c = 0; c < p->n_constraints; ++c) {
+        const bool in_i = local_of[p->c_i[c]] >= 0, in_j = local_of[p->c_j[c]] >= 0;
+        if (in_i && in_j) { ci.push_back((uint32_t)local_of[p->c_i[c]]); cj.push_back((uint32_t)local_of[p->c_j[c]]); cd.push_back(p->c_dist[c]); cs.push_back(p->c_sigma[c]); }
+        else if (in_i != in_j) ++dropped;
+      }
     lifcal_ba_problem sub = *p;
     sub.n_obs = n; sub.n_frames = nf; sub.n_points = (uint32_t)pts_ids.size(); sub.n_constraints = (uint32_t)ci.size();
     sub.u = u.data(); sub.v = v.data(); sub.mcx = mcx.data(); sub.mcy = mcy.data(); sub.pt = pt.data(); sub.fr = fr.data();
@@ -53,11 +72,12 @@ extern "C" int lifcal_ba_solve_windowed(const lifcal_ba_problem* p, const lifcal
     sub.c_i = ci.empty() ? nullptr : ci.data(); sub.c_j = cj.empty() ? nullptr : cj.data();
     sub.c_dist = cd.empty() ? nullptr : cd.data(); sub.c_sigma = cs.empty() ? nullptr : cs.data();
     lifcal_ba_window_report rep{};
-    rep.first_frame = a; rep.n_frames = nf; rep.n_points = sub.n_points; rep.n_obs = n;
+    rep.first_frame = a; rep.n_frames = nf; rep.n_points = sub.n_points; rep.n_obs = n; rep.n_dropped_constraints = dropped;
     int rc = 0;
     if (n > 0) {
       lifcal_ba_handle* h = nullptr;
       rc = lifcal_ba_create(&sub, &opt, &h);
+      if (rc != 0) h = nullptr;
       if (rc == 0) {
         if (comm_template) {   // the collectives of the caller's handle serve every window (the communicator stays the caller's)
           h->hook = comm_template->hook; h->hook_ctx = comm_template->hook_ctx;
@@ -70,9 +90,13 @@ extern "C" int lifcal_ba_solve_windowed(const lifcal_ba_problem* p, const lifcal
           rep.n_fixed_frames = std::min(nf, overlap_frames);
           rc = lifcal_ba_set_fixed_frames(h, fixed.data());
         }
-        if (rc == 0) rc = lifcal_ba_solve(h, &rep.summary);
-        lifcal_ba_destroy(h);
       }
+      rc = windowed_agree(comm_template, opt, dev_flag, rc);        // nobody enters the solve's collectives alone (all zero or all non-zero from here)
+      if (rc == 0) {
+        rc = lifcal_ba_solve(h, &rep.summary);
+        rc = windowed_agree(comm_template, opt, dev_flag, rc);
+      }
+      if (h) lifcal_ba_destroy(h);
       if (rc == 0) for (size_t j = 0; j < pts_ids.size(); ++j) for (int c = 0; c < 3; ++c) p->pts[3 * (size_t)pts_ids[j] + c] = pts[3 * j + c];
     }
     for (uint32_t q : pts_ids) local_of[q] = -1;
@@ -82,4 +106,19 @@ extern "C" int lifcal_ba_solve_windowed(const lifcal_ba_problem* p, const lifcal
     if (b == F) break;
   }
   return 0;
+}
+
+extern "C" int lifcal_ba_solve_windowed(const lifcal_ba_problem* p, const lifcal_ba_options* o, uint32_t window_frames, uint32_t overlap_frames,
+                                        lifcal_ba_handle* comm_template, lifcal_ba_window_report* per_window, uint32_t* n_windows) {
+  double* dev_flag = nullptr;
+  if (comm_template && o && o->world_size > 1 && hipMalloc((void**)&dev_flag, sizeof(double)) != hipSuccess) return LIFCAL_BA_ERR_NOMEM;
+  int rc;
+  try {
+    rc = solve_windowed_impl(p, o, window_frames, overlap_frames, comm_template, per_window, n_windows, dev_flag);
+  } catch (const std::bad_alloc&) {   // (no exception crosses the C ABI)
+    g_last_error = "lifcal_ba_solve_windowed: out of host memory";
+    rc = LIFCAL_BA_ERR_NOMEM;
+  }
+  if (dev_flag) (void)hipFree(dev_flag);
+  return rc;
 }

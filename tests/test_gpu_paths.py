@@ -73,6 +73,39 @@ def test_group_splitting_does_not_change_the_result(built, tmp_path, split):
 
 
 @pytest.mark.parametrize("spec_args", [
+    "24, 160, 6, 0xF06, 1211, outlier_fraction=0.02",
+    "12, 90, None, 0x501, 1212",
+    "30, 250, 9, 0xD04, 1213",
+    "40, 400, 12, 0x506, 1214",
+    "60, 700, 8, 0xF06, 1215, outlier_fraction=0.02",
+])
+def test_two_kernel_sweep_agrees(built, tmp_path, spec_args):
+    """k_front4 + k_back4 (LIFCAL_SWEEP_KERNEL=4: tiles of whole points worked by evaluator / accumulator / emitter waves, the point
+    elimination in its own 1024-thread kernel; sweep4.hpp) against the global-atomic kernels and against the default k_sweep3"""
+    a = run_child(tmp_path, spec_args, {"LIFCAL_SWEEP_KERNEL": "4"}, "k4")
+    b = run_child(tmp_path, spec_args, {"LIFCAL_DISABLE_V2": "1"}, "ref")
+    c = run_child(tmp_path, spec_args, {}, "k3")
+    assert int(a["chunks"]) >= 1
+    for o in (b, c):
+        assert abs(float(a["cost"]) - float(o["cost"])) <= 1e-13 * float(o["cost"])
+        assert scaled_max_err(a["S"], o["S"]) < 1e-10 and vec_err(a["rhs"], o["rhs"]) < 1e-10
+        assert vec_err(a["pg"], o["pg"]) < 1e-11 and vec_err(a["ui"], o["ui"]) < 1e-10
+
+
+def test_two_kernel_sweep_follows_the_oracle_through_a_solve(built, monkeypatch):
+    """the same LM trajectory as the oracle with LIFCAL_SWEEP_KERNEL=4 (diagonal-only pass, Jacobi scaling, candidate evaluation)"""
+    import oracle
+    monkeypatch.setenv("LIFCAL_SWEEP_KERNEL", "4")
+    sc = scene.make_scene(S(30, 300, 8, 0xF06, 1216, outlier_fraction=0.02))
+    pa = problem(sc)
+    with BundleAdjustment(pa) as ba:
+        s = ba.performBundleAdjustment()
+    so = oracle.solve(problem(sc), threads=4)
+    assert (s.iterations, s.successful_steps, s.termination) == (so.iterations, so.successful_steps, so.termination)
+    assert abs(s.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+
+
+@pytest.mark.parametrize("spec_args", [
     "24, 160, 6, 0xF06, 1207, outlier_fraction=0.02",
     "12, 90, None, 0x501, 1208",
     "30, 250, 9, 0xD04, 1209",

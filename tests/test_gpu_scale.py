@@ -63,6 +63,56 @@ def test_metric_point_properties(built):
     assert s.final_cost < 1e-10 * s.initial_cost
 
 
+def _web_scene(name):
+    """a *_web workload as bench.py builds it: the lenses of every image point chosen by the library's GPU port of the reference's
+    generator (lifcal_mla_project)"""
+    from lifcal_amd.mla import MicroLensGrid
+    spec = scene.baseline_spec(name)
+    grid = MicroLensGrid(spec.raw_width, spec.raw_height, spec.lens_diameter, spec.lens_base_y, spec.grid_rotation, spec.grid_offset, True, device=0)
+
+    def selector(img_x, img_y, img_vd, img_fr, img_pt, scale):
+        o = grid.projectPointsToRawImage(img_x, img_y, img_vd, int(scale), fr=img_fr, pt=img_pt)
+        return o.src, o.mcx, o.mcy
+    try:
+        return scene.make_scene(spec, lens_selector=selector)
+    finally:
+        grid.close()
+
+
+def test_benchmarked_workload_full_matrix_parity(built):
+    """metric_web — the workload BENCH is quoted on — through one sweep against the oracle on every host thread: cost, the whole
+    reduced matrix, right-hand side, point gradients (the oracle takes about a second on the GPU box's host)"""
+    sc = _web_scene("metric_web")
+    assert 0.95e6 < sc.n_obs < 1.05e6
+    ref = oracle.sweep(problem(sc), radius=1e4, threads=oracle.hardware_threads())
+    with BundleAdjustment(problem(sc)) as ba:
+        got = ba.sweep(1e4, want_matrices=True)
+    assert abs(got.cost - ref.cost) <= 1e-12 * ref.cost
+    assert scaled_max_err(got.S, ref.S) < 1e-8
+    assert vec_err(got.rhs, ref.rhs) < 1e-8 and vec_err(got.point_gradient, ref.point_gradient) < 1e-10
+
+
+def test_cfg4_spot_checks_against_the_oracle(built):
+    """BASELINE configs[3] (1000 frames, 50 k points, ~2.4 M observations): the oracle's dense 6017^2 elimination is too slow for a
+    unit test, so the comparators are (1) its cost on the whole problem, (2) its sweep on three SUB-PROBLEMS — the observations of a
+    40-frame window — whose pose gradients J_f^T r are sums over the frame's own observations, i.e. equal to the full problem's"""
+    sc = scene.make_scene(scene.baseline_spec("cfg4"))
+    with BundleAdjustment(problem(sc)) as ba:
+        full = ba.sweep(1e4, want_matrices=True)
+    c = oracle.cost(problem(sc), threads=oracle.hardware_threads())
+    assert abs(full.cost - c) <= 1e-11 * c
+    F = sc.spec.n_frames
+    views = sc.views0.reshape(-1, 6); pts = sc.pts0.reshape(-1, 3)
+    for f0 in (0, F // 2 - 20, F - 40):
+        sel = (sc.fr >= f0) & (sc.fr < f0 + 40)
+        used = np.unique(sc.pt[sel])
+        remap = np.zeros(sc.spec.n_points, np.int64); remap[used] = np.arange(len(used))
+        sub = capi.ProblemArrays(sc.u[sel], sc.v[sel], sc.mcx[sel], sc.mcy[sel], remap[sc.pt[sel]], sc.fr[sel] - f0, sc.cam0,
+                                 views[f0:f0 + 40].reshape(-1), pts[used].reshape(-1), sc.spx, sc.scale, sc.config, use_constraints=0)
+        ref = oracle.sweep(sub, radius=1e4, threads=oracle.hardware_threads())
+        assert vec_err(full.gradient_reduced[17 + 6 * f0:17 + 6 * (f0 + 40)], ref.gradient_reduced[17:17 + 240]) < 1e-9
+
+
 def test_rccl_single_rank_and_hook_paths(built):
     """world_size = 1 through a real RCCL communicator must not change anything; a summing hook doubles as a
     2-rank rehearsal on one GPU: rank r owns half the points, the hook adds the other rank's partial block."""

@@ -18,6 +18,6 @@ for d in "abc":
             k = r["Kernel_Name"].split("(")[0][:40]
             acc[k][r["Counter_Name"]][0] += float(r["Counter_Value"]); acc[k][r["Counter_Name"]][1] += 1
     for k, v in acc.items():
-        if "sweep" in k:
+        if "sweep" in k or "front4" in k or "back4" in k:
             print(k, {c: round(x[0] / max(x[1], 1)) for c, x in v.items()})
 PY

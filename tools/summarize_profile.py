@@ -41,18 +41,22 @@ for k in sorted(set(fetch) | set(write), key=lambda k: -(fetch.get(k, 0) + write
     traffic[short] = fb + wb
 json.dump(traffic, open(os.path.join(out, "traffic_by_kernel.json"), "w"), indent=1)
 
-# SQ issue counters of the sweep kernel (separate passes pmc_sq1 / pmc_sq2), averaged per launch
-print("\n== SQ counters per launch (k_sweep3; SQ_* cycle counters count quad-cycles) ==")
-sq = {}
-for pat in ("pmc_sq1/**/*counter_collection.csv", "pmc_sq2/**/*counter_collection.csv"):
+# SQ issue counters of the sweep kernels (separate passes pmc_sq*), averaged per launch
+print("\n== SQ counters per launch (sweep kernels; SQ_* cycle counters count quad-cycles) ==")
+sq = defaultdict(dict)
+for pat in ("pmc_sq1/**/*counter_collection.csv", "pmc_sq2/**/*counter_collection.csv", "pmc_sq3/**/*counter_collection.csv"):
     acc = defaultdict(lambda: [0.0, 0])
     for f in find(pat):
         for r in csv.DictReader(open(f)):
-            if "k_sweep3" not in r["Kernel_Name"]:
+            name = r["Kernel_Name"]
+            if not any(k in name for k in ("k_sweep3", "k_front4", "k_back4")):
                 continue
-            acc[r["Counter_Name"]][0] += float(r["Counter_Value"]); acc[r["Counter_Name"]][1] += 1
-    for k, v in acc.items():
-        sq[k] = v[0] / max(v[1], 1)
-for k in sorted(sq):
-    print(f"  {k:24s} {sq[k]:16.0f}")
+            short = name.split("(")[0].replace("void lifcal::", "")
+            acc[(short, r["Counter_Name"])][0] += float(r["Counter_Value"]); acc[(short, r["Counter_Name"])][1] += 1
+    for (short, k), v in acc.items():
+        sq[short][k] = v[0] / max(v[1], 1)
+for short in sorted(sq):
+    print(f" {short}")
+    for k in sorted(sq[short]):
+        print(f"  {k:24s} {sq[short][k]:16.0f}")
 json.dump(sq, open(os.path.join(out, "sq_counters.json"), "w"), indent=1)
