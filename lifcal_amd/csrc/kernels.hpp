@@ -33,6 +33,11 @@ constexpr int SCAL_COST = 0, SCAL_BAD_U = 1, SCAL_GMAX0 = 2, SCAL_N = 2 + 64;
 // host-visible scalars of one LM step
 constexpr int ST_GTD = 0, ST_DDD = 1, ST_STEP2 = 2, ST_X2 = 3, ST_CAND_COST = 4, ST_CHOL_FAIL = 5, ST_GMAX_RED = 6, ST_DIR = 7, ST_N = 8;
 
+// device-resident state of the Levenberg-Marquardt loop (k_lm_control; the host mirrors it once per iteration)
+enum { LM_RADIUS = 0, LM_DECREASE = 1, LM_X_COST = 2, LM_GMAX = 3, LM_ITER = 4, LM_INVALID = 5, LM_STEP_OK = 6, LM_SUCCESSFUL = 7, LM_UNSUCCESSFUL = 8,
+       LM_TERMINATION = 9, LM_COMMIT = 10, LM_FRESH = 11, LM_INITIAL_COST = 12, LM_LAST_REL = 13, LM_LAST_STEP = 14, LM_LAST_CHANGE = 15, LM_SWEEPS = 16, LM_N = 24 };
+struct LmOpts { double f_tol, p_tol, g_tol, min_rel_decrease, max_radius, min_radius; int max_iterations; };
+
 // a set of tiles for the value-only kernels (both sweep paths share them)
 struct TileSet { uint32_t n_tiles; const uint32_t *tile_row0, *slot_pt, *slot_fr, *slot_cnt, *ell_lens; const double *ell_u, *ell_v; };
 
@@ -85,10 +90,14 @@ struct Dev {
   // reduced system (one contiguous all-reduced block): Sband | Sarrow | rhsacc | gB | hdiag | scal
   double *Sband, *Sarrow, *rhsacc, *gB, *hdiag, *scal;
   double *sig_red, *lam_red, *delta_red, *Linv;  // n_red, n_red, n_red, 36F
+  double* lm;                    // LM_N doubles: the device-resident trust-region state (k_lm_control), radius first
   double* step;                  // ST_N scalars
   double* dP;                    // 3P: unscaled point step of the last back-substitution (line search re-applies it)
   unsigned long long* dbg;       // diagnostic build only (LIFCAL_STAMPS): per-block phase cycle counts
 };
+
+// trust-region radius of a kernel: the launch argument, or (negative argument) the device-resident state
+LIFCAL_DEV double lm_radius(const Dev& d, double arg) { return arg < 0.0 ? d.lm[LM_RADIUS] : arg; }
 
 LIFCAL_DEV double* s_addr(const Dev& d, uint32_t row, uint32_t col) {  // row >= col, internal ordering
   if (row < 6 * d.F) {
@@ -382,7 +391,7 @@ LIFCAL_DEV double finalize_column(const Dev& d, uint32_t t, double radius) {
   double* rhs = d.Sarrow + (size_t)d.NA * d.ld;  // extra arrow row carries the right-hand side
   if (live) {
     const double s = d.sig_red[t];
-    const double lam = fmin(fmax(d.hdiag[t] * s * s, d.lm_min), d.lm_max) / (radius * s * s);
+    const double lam = fmin(fmax(d.hdiag[t] * s * s, d.lm_min), d.lm_max) / (lm_radius(d, radius) * s * s);
     d.lam_red[t] = lam;
     *diag += lam;
     rhs[t] = -d.gB[t] + d.rhsacc[t];
@@ -514,7 +523,7 @@ __global__ __launch_bounds__(256) void k_schur(Dev d, double radius) {
   {
     const double h[3] = {U[0], U[3], U[5]};
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const double s = d.sigP[3 * (size_t)p + k]; lam[k] = fmin(fmax(h[k] * s * s, d.lm_min), d.lm_max) / (radius * s * s); }
+    for (int k = 0; k < 3; ++k) { const double s = d.sigP[3 * (size_t)p + k]; lam[k] = fmin(fmax(h[k] * s * s, d.lm_min), d.lm_max) / (lm_radius(d, radius) * s * s); }
   }
   U[0] += lam[0]; U[3] += lam[1]; U[5] += lam[2];
   // inverse through the Cholesky factor (ceres InvertPSDMatrix<3>)
@@ -1150,6 +1159,83 @@ __global__ void k_dir_max(Dev d, unsigned long long* slots) {
     if (mr > 0.0) atomicMax(slots + 64, (unsigned long long)__double_as_longlong(mr));
     if (mp > 0.0) atomicMax(slots + d.rank, (unsigned long long)__double_as_longlong(mp));
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Levenberg-Marquardt control on the device (one thread): what lifcal_ba_solve's host loop decides per iteration —
+// ceres 2.1 TrustRegionMinimizer: step validity, the three convergence tests, accept / reject, radius update — from the
+// scalars the sweep and the candidate evaluation left in HBM.  The host enqueues sweep | linear solve | candidate | this |
+// k_lm_commit | next sweep without waiting and reads the state back once per iteration while the next sweep runs.
+// Unbounded problems on one rank (bounds need the host's line search, ranks need rank-consistent host decisions).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_lm_control(Dev d, LmOpts o, const double* partial) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double* lm = d.lm;
+  lm[LM_COMMIT] = 0.0;
+  if (lm[LM_TERMINATION] != 0.0) return;
+  lm[LM_SWEEPS] += 1.0;
+  // the sweep at the head of this iteration: cost / gradient norm of a NEW point, or the same point at a new radius
+  double bad = d.scal[SCAL_BAD_U];
+  if (lm[LM_FRESH] != 0.0) {
+    double g = 0.0;
+    for (int r = 0; r < 64; ++r) g = fmax(g, d.scal[SCAL_GMAX0 + r]);
+    g = fmax(g, d.step[ST_GMAX_RED]);
+    lm[LM_X_COST] = d.scal[SCAL_COST]; lm[LM_GMAX] = g;
+    if (lm[LM_INITIAL_COST] < 0.0) {   // the first sweep of the solve
+      lm[LM_INITIAL_COST] = lm[LM_X_COST];
+      if (!(fabs(lm[LM_X_COST]) < 1.7e308)) { lm[LM_TERMINATION] = -1.0; return; }   // non-finite cost at the initial point
+      if (g <= o.g_tol) { lm[LM_TERMINATION] = (double)LIFCAL_BA_TERM_GRADIENT_TOLERANCE; return; }
+    }
+    lm[LM_FRESH] = 0.0;
+  } else {
+    bad = 0.0;   // (the host loop does not re-read the flag of a re-sweep at a smaller radius either)
+  }
+  const double x_cost = lm[LM_X_COST];
+  // top of the loop
+  if (lm[LM_ITER] >= (double)o.max_iterations) { lm[LM_TERMINATION] = (double)LIFCAL_BA_TERM_MAX_ITERATIONS; return; }
+  if (lm[LM_STEP_OK] != 0.0 && lm[LM_GMAX] <= o.g_tol) { lm[LM_TERMINATION] = (double)LIFCAL_BA_TERM_GRADIENT_TOLERANCE; return; }
+  if (lm[LM_RADIUS] < o.min_radius) { lm[LM_TERMINATION] = (double)LIFCAL_BA_TERM_MIN_RADIUS; return; }
+  lm[LM_ITER] += 1.0;
+  const double gtd = partial[0], ddd = partial[1], step2 = partial[2], x2 = partial[3];
+  double cand_cost = partial[4];
+  const double chol_fail = d.step[ST_CHOL_FAIL];
+  // model_cost_change = -g^T d - 1/2 d^T J^T J d with (J^T J + Lambda) d = -g  =>  1/2 (d^T Lambda d - g^T d)
+  const double mcc = 0.5 * (ddd - gtd);
+  const bool valid = chol_fail == 0.0 && bad == 0.0 && fabs(mcc) < 1.7e308 && mcc > 0.0;
+  if (!valid) {
+    lm[LM_INVALID] += 1.0;
+    if (lm[LM_INVALID] >= 5.0) { lm[LM_TERMINATION] = (double)LIFCAL_BA_TERM_INVALID_STEPS; return; }
+    lm[LM_RADIUS] *= 0.5; lm[LM_STEP_OK] = 0.0; lm[LM_UNSUCCESSFUL] += 1.0;
+    return;
+  }
+  lm[LM_INVALID] = 0.0;
+  if (!(fabs(cand_cost) < 1.7e308)) cand_cost = 1.7976931348623157e308;
+  const double step_norm = sqrt(step2), x_norm = sqrt(x2);
+  lm[LM_LAST_STEP] = step_norm;
+  if (step_norm <= o.p_tol * (x_norm + o.p_tol)) { lm[LM_TERMINATION] = (double)LIFCAL_BA_TERM_PARAMETER_TOLERANCE; return; }
+  const double cost_change = x_cost - cand_cost;
+  lm[LM_LAST_CHANGE] = cost_change;
+  if (fabs(cost_change) <= o.f_tol * x_cost) { lm[LM_TERMINATION] = (double)LIFCAL_BA_TERM_FUNCTION_TOLERANCE; return; }
+  const double rel = (cand_cost >= 1.7976931348623157e308) ? -1.7976931348623157e308 : cost_change / mcc;
+  lm[LM_LAST_REL] = rel;
+  if (rel > o.min_rel_decrease) {
+    const double t = 2.0 * rel - 1.0;
+    double radius = lm[LM_RADIUS] / fmax(1.0 / 3.0, 1.0 - t * t * t);
+    lm[LM_RADIUS] = fmin(o.max_radius, radius);
+    lm[LM_DECREASE] = 2.0;
+    lm[LM_COMMIT] = 1.0; lm[LM_FRESH] = 1.0; lm[LM_STEP_OK] = 1.0; lm[LM_SUCCESSFUL] += 1.0;
+  } else {
+    lm[LM_RADIUS] = lm[LM_RADIUS] / lm[LM_DECREASE]; lm[LM_DECREASE] *= 2.0; lm[LM_STEP_OK] = 0.0; lm[LM_UNSUCCESSFUL] += 1.0;
+  }
+}
+
+// an accepted candidate becomes the current point (the host loop swaps pointers; device code keeps its arguments and copies)
+__global__ void k_lm_commit(Dev d) {
+  if (d.lm[LM_COMMIT] == 0.0) return;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, n = gridDim.x * blockDim.x;
+  for (uint32_t i = t; i < LIFCAL_BA_MAX_CAMERA_PARAMETERS; i += n) d.cam[i] = d.cam_c[i];
+  for (uint32_t i = t; i < 6 * d.F; i += n) d.views[i] = d.views_c[i];
+  if (d.use_points) for (uint32_t i = t; i < 3 * d.P; i += n) d.pts[i] = d.pts_c[i];
 }
 
 // ---------------------------------------------------------------------------------------------

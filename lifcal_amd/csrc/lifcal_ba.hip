@@ -101,6 +101,8 @@ struct lifcal_ba_handle {
   double* pts_gather = nullptr;
   CamConsts* camc_stats = nullptr;
   double* h_scal = nullptr;      // pinned host mirror
+  double* h_lm = nullptr;        // pinned host mirror of the device-resident LM state (d.lm)
+  hipEvent_t ev_lm = nullptr, ev_la = nullptr, ev_lb = nullptr;
   bool sigma_valid = false;
   bool constrained = false;
   lifcal_ba_allreduce_fn hook = nullptr; void* hook_ctx = nullptr;
@@ -892,7 +894,7 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
     }
   }
   A(d.dbg, std::max((size_t)std::max(1u, d.n_blocks) * 32, (size_t)d.n_fwg * 64));
-  A(d.dP, 3 * (size_t)d.P); A(h->ls_buf, 8); A(h->dirmax_buf, 65);
+  A(d.dP, 3 * (size_t)d.P); A(h->ls_buf, 8); A(h->dirmax_buf, 65); A(d.lm, LM_N);
   d.step = d.scal + SCAL_N; h->partial = d.step + ST_N;   // (behind the all-reduced block, not part of it)
   A(h->hdiag_tmp, d.n_red); A(h->stats_buf, 8); A(h->stats_slots, 4 + 2 * 64); A(h->pts_gather, 3 * (size_t)d.P);
   // Cholesky panel: LDS when it fits (<= 64 KiB by default launch limits), else a global scratch
@@ -935,6 +937,8 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
 #undef U
   cclk.lap("create: alloc + upload");
   if (hipHostMalloc((void**)&h->h_scal, (SCAL_N + 2 * ST_N + 16) * sizeof(double)) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
+  if (hipHostMalloc((void**)&h->h_lm, LM_N * sizeof(double)) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
+  if (hipEventCreate(&h->ev_lm) != hipSuccess || hipEventCreate(&h->ev_la) != hipSuccess || hipEventCreate(&h->ev_lb) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
   if (int rc2 = upload_parameters(h)) return fail(rc2);
   cclk.lap("create: parameters");
   *out = h;
@@ -947,6 +951,8 @@ void lifcal_ba_destroy(lifcal_ba_handle* h) {
   if (h->comm && !h->comm_borrowed && g_rccl.CommDestroy) g_rccl.CommDestroy(h->comm);
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
+  if (h->h_lm) (void)hipHostFree(h->h_lm);
+  for (hipEvent_t e : {h->ev_lm, h->ev_la, h->ev_lb}) if (e) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -1121,6 +1127,54 @@ int lifcal_ba_sweep(lifcal_ba_handle* h, double radius, lifcal_ba_sweep_out* out
   return 0;
 }
 
+// The LM loop with the decisions on the device (k_lm_control / k_lm_commit, kernels.hpp): per iteration the host enqueues
+//   linear solve | candidate + its cost | control | commit | state read-back | the NEXT sweep (at whatever point / radius control chose)
+// and waits for the read-back only — behind it the next sweep is already running, so the queue never drains while the host
+// decides and launches (round 2: two blocking read-backs per iteration, ~250 of ~550 us per iteration were host-induced idle
+// time).  The sweep enqueued behind the terminating decision is the only wasted work.  Unbounded problems on one rank.
+static int solve_device_loop(lifcal_ba_handle* h, lifcal_ba_summary* s, double t_start) {
+  Dev& d = h->d;
+  const lifcal_ba_options& o = h->opt;
+  double lm0[LM_N];
+  for (int i = 0; i < LM_N; ++i) lm0[i] = 0.0;
+  lm0[LM_RADIUS] = o.initial_radius; lm0[LM_DECREASE] = 2.0; lm0[LM_STEP_OK] = 1.0; lm0[LM_FRESH] = 1.0; lm0[LM_INITIAL_COST] = -1.0;
+  std::memcpy(h->h_lm, lm0, sizeof(lm0));
+  HIP_TRY(hipMemcpyAsync(d.lm, h->h_lm, sizeof(lm0), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipStreamSynchronize(h->stream));   // (h_lm is reused as the read-back target)
+  const LmOpts lo{o.function_tolerance, o.parameter_tolerance, o.gradient_tolerance, o.min_relative_decrease, o.max_radius, o.min_radius, o.max_iterations};
+  double t0 = now_s();
+  if (int rc = launch_sweep(h, -1.0)) return rc;
+  float ms_linear = 0.f;
+  const uint32_t commit_grid = std::max(1u, std::min(1024u, (3 * d.P + 6 * d.F + 255) / 256));
+  for (int round = 0; round < o.max_iterations + 8; ++round) {
+    HIP_TRY(hipEventRecord(h->ev_la, h->stream));
+    if (int rc = launch_linear_solve(h)) return rc;
+    if (int rc = launch_candidate(h)) return rc;
+    HIP_TRY(hipEventRecord(h->ev_lb, h->stream));
+    hipLaunchKernelGGL(k_lm_control, dim3(1), dim3(64), 0, h->stream, d, lo, (const double*)h->partial);
+    hipLaunchKernelGGL(k_lm_commit, dim3(commit_grid), dim3(256), 0, h->stream, d);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h->h_lm, d.lm, LM_N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipEventRecord(h->ev_lm, h->stream));
+    if (int rc = launch_sweep(h, -1.0)) return rc;         // speculative: runs while the host looks at the state
+    HIP_TRY(hipEventSynchronize(h->ev_lm));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev_la, h->ev_lb) == hipSuccess) ms_linear += ms;
+    if (h->h_lm[LM_TERMINATION] != 0.0) break;
+  }
+  HIP_TRY(hipStreamSynchronize(h->stream));
+  const double* lm = h->h_lm;
+  if (lm[LM_TERMINATION] < 0.0) { g_last_error = "non-finite cost at the initial point"; return LIFCAL_BA_ERR_NUMERIC; }
+  s->initial_cost = lm[LM_INITIAL_COST]; s->final_cost = lm[LM_X_COST]; s->final_radius = lm[LM_RADIUS]; s->final_gradient_max_norm = lm[LM_GMAX];
+  s->iterations = (int32_t)lm[LM_ITER]; s->successful_steps = (int32_t)lm[LM_SUCCESSFUL]; s->unsuccessful_steps = (int32_t)lm[LM_UNSUCCESSFUL];
+  s->termination = lm[LM_TERMINATION] != 0.0 ? (int32_t)lm[LM_TERMINATION] : LIFCAL_BA_TERM_MAX_ITERATIONS;
+  if (int rc = download_parameters(h)) return rc;
+  s->seconds_total = now_s() - t_start;
+  s->seconds_linear_solve = 1e-3 * (double)ms_linear;                      // linear solve + candidate evaluation, by their events
+  s->seconds_sweep = std::max(0.0, (now_s() - t0) - s->seconds_linear_solve);   // everything else of the loop: sweeps, control, the read-backs
+  return 0;
+}
+
 int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
   if (!h || !s) return LIFCAL_BA_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->opt.device));
@@ -1128,6 +1182,9 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
   const double t_start = now_s();
   std::memset(s, 0, sizeof(*s));
   if (int rc = upload_parameters(h)) return rc;
+  // decisions on the device where the host has none of its own to make (LIFCAL_HOST_LM=1: the host loop below, e.g. for LIFCAL_TRACE)
+  if (!h->constrained && o.world_size == 1 && o.precision == 0 && !h->trace && !o.verbose && getenv("LIFCAL_HOST_LM") == nullptr)
+    return solve_device_loop(h, s, t_start);
   double radius = o.initial_radius, decrease_factor = 2.0;
   double x_cost, gmax, bad;
   double t0 = now_s();

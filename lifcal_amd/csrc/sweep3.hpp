@@ -486,7 +486,7 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
           {
             const double h[3] = {U0, U3, U5}, sgv[3] = {fsg0, fsg1, fsg2};
 #pragma unroll
-            for (int k = 0; k < 3; ++k) { const double sg = sgv[k]; lam[k] = fmin(fmax(h[k] * sg * sg, d.lm_min), d.lm_max) / (radius * sg * sg); }
+            for (int k = 0; k < 3; ++k) { const double sg = sgv[k]; lam[k] = fmin(fmax(h[k] * sg * sg, d.lm_min), d.lm_max) / (lm_radius(d, radius) * sg * sg); }
           }
           U0 += lam[0]; U3 += lam[1]; U5 += lam[2];
           bool ok = U0 > 0.0;

@@ -56,37 +56,102 @@ def solve_arm(sc, precision, tight):
     return pa, s, st
 
 
+def systems_at(sc, p_star):
+    """the reduced camera + pose system at a point in both arithmetics, (effectively) undamped and unscaled"""
+    out = []
+    for prec in (1, 0):
+        o = opts(prec); o.jacobi_scaling = 0; o.min_lm_diagonal = 1e-300
+        with BundleAdjustment(problem_at(sc, p_star), o) as ba:
+            out.append(ba.sweep(1e30, want_matrices=True))
+    return out
+
+
+def problem_at(sc, p):
+    return capi.ProblemArrays(sc.u, sc.v, sc.mcx, sc.mcy, sc.pt, sc.fr, p.cam, p.views, p.pts, sc.spx, sc.scale, sc.config)
+
+
+def scaled_pinv(S, rcond=1e-12):
+    """pseudo-inverse of the diagonally scaled matrix, and the number of directions dropped as null"""
+    d = np.sqrt(np.abs(np.diag(S)))
+    w, V = np.linalg.eigh(S / np.outer(d, d))
+    keep = w > rcond * w.max()
+    return ((V[:, keep] / w[keep]) @ V[:, keep].T) / np.outer(d, d), int((~keep).sum())
+
+
 @pytest.mark.parametrize("name", ["cfg2", "cfg3"])
 def test_fp32_arm_converges_to_the_fp64_arm(built, name):
-    """BASELINE configs[1] / configs[2] sizes.  With the reference's tolerances (f_tol 1e-6, src/CameraCalibration.cpp:958) two
-    trajectories stop within the slack those tolerances leave — the fp64 arm against ITSELF at tight tolerances moves the weakly
-    determined triple (fL, bL0, B) by several 1e-6 — so the north star's bar (converged intrinsics within 1e-6 relative) is
-    asserted where it is meaningful: both arms driven to convergence.  Costs are fp64 costs in both arms."""
+    """BASELINE configs[1] / configs[2] sizes, both arms driven to their minimisers (tight tolerances, ordered reductions: what is
+    left between them is arithmetic).  The bar is stated and derived, not fitted:
+      * fL, bL0, cx, cy: within 1e-5 relative of the fp64 arm (the north star's 1e-6 times the documented factor 10 for
+        single-precision evaluation; measured 1e-7 .. 3.5e-6);
+      * the reduced system H of the fp64 problem at its minimiser x* has an EXACT null space (eigenvalues 1e-16 .. 1e-18 of the largest,
+        seven directions with all poses and points free: the gauge of the scene — and it has components in B and bL0, i.e. these
+        data do not identify B on their own; LM's damping picks the representative).  Round 2 saw B "wander" by 5e-5 .. 5e-4 between
+        arms at a cost equal to 1e-13: that movement lies in this null space.  So the arms are compared MODULO it: the shift
+        x32 - x* (camera + poses) is split into its null part and the rest, shift_perp = H^+ H shift;
+      * every live slot of shift_perp, B and the distortion coefficients included, lies inside the ellipsoid of points the fp64 cost
+        cannot tell from its minimiser: |shift_perp_j| <= sqrt(2 dc [H^+]_jj), dc = cost64(x32) - cost64(x*) but no smaller than the
+        1e-10 relative to which the two costs are asserted equal; and the whole shift costs no more than dc: 1/2 shift^T H shift <= dc;
+      * the cause is the single-precision gradient: at x* the two arithmetics' reduced matrices agree to 2e-5, the gradients to 2e-4
+        of the size of the terms they cancel from."""
     sc = scene.make_scene(scene.baseline_spec(name))
     live = 5 + (sc.config & 3) + (2 if sc.config & 4 else 0)
     p0, s0, t0 = solve_arm(sc, 0, tight=True)
     p1, s1, t1 = solve_arm(sc, 1, tight=True)
-    rel = np.abs(p1.cam[:live] - p0.cam[:live]) / np.abs(p0.cam[:live])
-    # reference tolerances (f_tol 1e-6): where the fp64 arm itself stops relative to its converged point = the slack of every slot
-    q0, u0, _ = solve_arm(sc, 0, tight=False)
-    q1, u1, _ = solve_arm(sc, 1, tight=False)
-    slack = np.abs(q0.cam[:live] - p0.cam[:live]) / np.abs(p0.cam[:live])
-    # Measured (round 2): both arms converged, fL / bL0 / cx agree to 2e-7 .. 2e-6, cy to 2.5e-6, B to 5e-5 .. 8e-5, at a cost
-    # identical to 1e-10.  B (and the distortion coefficients) lie along a flat direction of these scenes — the fp64 arm itself
-    # moves B by several 1e-6 between the reference's tolerances and convergence (`slack`), and where along the valley a run
-    # stops is decided below the resolution of the cost.  The north star's 1e-6 is therefore asserted within a factor 10 on the
-    # well-determined slots and B is held to 5e-4.
-    assert rel[[0, 1, 3, 4]].max() < 3e-5, (rel, slack)                  # fL, bL0, cx, cy (measured 1e-7 .. 2.5e-6 with atomic sums, up to 1.3e-5 in bL0 on one run)
-    assert rel[2] < 1e-3 and rel[5:].max() < 5e-3, (rel, slack)         # B (measured 5e-5 .. 5e-4); k, p
+    x0 = p0.cam[:live]
+    rel = np.abs(p1.cam[:live] - x0) / np.abs(x0)
+    sw32, sw64 = systems_at(sc, p0)
+    # (1) the stated bar on the well-determined intrinsics, as returned
+    assert rel[[0, 1, 3, 4]].max() < 1e-5, rel
+    # (2) modulo the null space of the fp64 system: inside the cost-indistinguishable ellipsoid, slot by slot
+    shift = np.concatenate([p1.cam - p0.cam, p1.views - p0.views])       # canonical order of the reduced system: 17 camera slots, 6 F poses
+    Hp, n_null = scaled_pinv(sw64.S)
+    perp = Hp @ (sw64.S @ shift)
+    dc = max(s1.final_cost - s0.final_cost, 0.0) + 1e-10 * s0.final_cost
+    bound = np.sqrt(2.0 * dc * np.diag(Hp)[:live])
+    rel_perp = np.abs(perp[:live]) / np.abs(x0)
+    print(f"[{name}] null directions {n_null}; relative shift of the fp32 arm {rel}\n[{name}] modulo the null space {rel_perp}\n[{name}] cost-ellipsoid bound {bound / np.abs(x0)}")
+    assert n_null == 7
+    assert np.all(np.abs(perp[:live]) <= bound + 1e-7 * np.abs(x0)), (rel_perp, bound / np.abs(x0))
+    assert rel_perp[:5].max() < 5e-6, rel_perp                              # ... where fL, bL0, B, cx, cy meet 5x the north star (measured 1e-7 .. 1.6e-6)
+    assert 0.5 * shift @ sw64.S @ shift <= dc
+    # (3) the cause: single-precision evaluation of the gradient
+    g_terms = np.sqrt(np.abs(np.diag(sw64.S)) * 2.0 * s0.final_cost)       # |J_j| |r|: the size of the sums the gradient entries cancel from
+    assert np.all(np.abs(sw32.gradient_reduced - sw64.gradient_reduced) <= 2e-4 * g_terms + 1e-300)
+    assert scaled_max_err(sw32.S, sw64.S) < 2e-5
     assert abs(s1.final_cost - s0.final_cost) <= 1e-10 * s0.final_cost
     assert abs(t1.std_x - t0.std_x) < 1e-8 and abs(t1.std_y - t0.std_y) < 1e-8
     c1 = oracle.cost(p1, threads=oracle.hardware_threads())              # the reported cost is the fp64 cost of the returned point
     assert abs(c1 - s1.final_cost) <= 1e-9 * c1
-    # reference tolerances: same iteration count (+-2), same cost to 1e-8, parameters inside the termination slack
+    # reference tolerances (f_tol 1e-6, src/CameraCalibration.cpp:958): both arms stop inside the slack those tolerances leave — the
+    # distance of the fp64 arm's stopping point from its own minimiser, slot by slot (c = 3)
+    q0, u0, _ = solve_arm(sc, 0, tight=False)
+    q1, u1, _ = solve_arm(sc, 1, tight=False)
+    slack = np.abs(q0.cam[:live] - x0) / np.abs(x0)
     assert u1.termination in (1, 2) and abs(u1.iterations - u0.iterations) <= 2
     assert abs(u1.final_cost - u0.final_cost) <= 1e-8 * u0.final_cost
     rel_d = np.abs(q1.cam[:live] - q0.cam[:live]) / np.abs(q0.cam[:live])
-    assert rel_d[[0, 1, 3, 4]].max() < 5e-5 and rel_d[2] < 2e-3, (rel_d, slack)
+    assert np.all(rel_d <= np.maximum(1e-6, 3.0 * slack) + rel), (rel_d, slack, rel)
+
+
+def test_fp64_and_fp32_arms_against_the_oracles_fp64_solve(built):
+    """per-slot deviation of BOTH arms from the ORACLE's fp64 solve (BASELINE configs[1], reference tolerances): the fp64 arm meets the
+    north star's 1e-6, the fp32 arm the documented 1e-5 on fL, bL0, cx, cy and the termination slack elsewhere"""
+    sc = scene.make_scene(scene.baseline_spec("cfg2"))
+    live = 5 + (sc.config & 3) + (2 if sc.config & 4 else 0)
+    po = problem(sc)
+    so = oracle.solve(po, threads=oracle.hardware_threads())
+    q0, u0, _ = solve_arm(sc, 0, tight=False)
+    q1, u1, _ = solve_arm(sc, 1, tight=False)
+    x = po.cam[:live]
+    r0 = np.abs(q0.cam[:live] - x) / np.abs(x); r1 = np.abs(q1.cam[:live] - x) / np.abs(x)
+    assert (u0.iterations, u0.termination) == (so.iterations, so.termination)
+    assert r0.max() < 1e-6, r0
+    assert abs(u1.iterations - so.iterations) <= 2 and abs(u1.final_cost - so.final_cost) <= 1e-8 * so.final_cost
+    assert r1[[0, 1, 3, 4]].max() < 1e-5, r1
+    p0, _, _ = solve_arm(sc, 0, tight=True)
+    slack = np.abs(q0.cam[:live] - p0.cam[:live]) / np.abs(p0.cam[:live])
+    assert np.all(r1 <= np.maximum(1e-5, 30.0 * slack)), (r1, slack)       # B, k, p: inside the slack of the reference's own tolerances
 
 
 def test_cfg5_recalibration_in_fp32_arithmetic(built):
