@@ -360,7 +360,12 @@ def main():
         p_loc = info.n_points_local if strong else spec.n_points   # per-rank share of the algorithmic bytes (rank 0's shard)
         b_obs = 24 if args.precision == 1 else 40   # SURVEY.md 8(d); the fp32 stream this library reads is 12 B per observation (du, dv, lens index)
         b_kernel = accumulate_kernel_bytes(n_loc, p_loc, spec.n_frames, b_obs)
-        b_sweep = algorithmic_bytes(n_loc, p_loc, spec.n_frames, 17 + 6 * spec.n_frames, b_obs)
+        n_red_loc = 17 + 6 * spec.n_frames
+        # what the band + arrow layout of the reduced system stores: F (bw + 1) pose blocks of 36 + (NA + 1) arrow rows
+        nc_live = 5 + (spec.config & 3) + (2 if spec.config & 4 else 0)
+        na = nc_live + 3 * int(info.n_promoted)
+        stored_doubles = F_tot * int(info.max_window_frames) * 36 + (na + 1) * (6 * F_tot + na + 1)
+        b_sweep = algorithmic_bytes(n_loc, p_loc, spec.n_frames, n_red_loc, b_obs)
         t_kernel = prof.ms_accumulate * 1e-3
         t_total = prof.ms_total * 1e-3
         achieved = b_kernel / t_kernel / 1e9
@@ -381,8 +386,11 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
                          "traffic": load_traffic(args.workload)[0], "traffic_source": load_traffic(args.workload)[1],
                          "algorithmic_bytes_per_launch": b_kernel, "kernel_ms": prof.ms_accumulate,
+                         "special_points": int(prof.special_points),   # points on the global-atomic kernels (their time is in ms_outside_dominant_kernel)
                          "whole_sweep": {"algorithmic_bytes": b_sweep, "ms": prof.ms_total, "ms_outside_dominant_kernel": prof.ms_schur,
-                                         "achieved": b_sweep / t_total / 1e9, "frac": b_sweep / t_total / HBM_PEAK}},
+                                         "achieved": b_sweep / t_total / 1e9, "frac": b_sweep / t_total / HBM_PEAK,
+                                         # SURVEY's formula charges S dense (n_red (n_red + 1) / 2 doubles); the band + arrow layout stores this much of it:
+                                         "bytes_moved_actual": b_sweep - 8 * (n_red_loc * (n_red_loc + 1) // 2) + 8 * stored_doubles}},
             "cost": last.cost,
             "solve": solve,
         }

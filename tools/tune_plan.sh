@@ -1,8 +1,9 @@
 #!/bin/bash
-# tuning aid: bench line for several lane split sizes / block counts (run on the GPU box via gpurun)
-run() { timeout -k 10 120 python bench.py --no-cpu-baseline --no-solve --steps 30 2>/dev/null | python -c "
-import sys,json; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', '%.3f G obs/s  kernel %.4f ms' % (j['value']/1e9, j['roofline']['kernel_ms']))"; }
-run auto
-for t in 0 3 4 5 6 8; do export LIFCAL_GROUP_SPLIT=$t; run split=$t; done
-unset LIFCAL_GROUP_SPLIT
-for b in 128 192 255 256 320 384 512; do export LIFCAL_V2_BLOCKS=$b; run blocks=$b; done
+# Sweeps the planner's cost-model constants (LIFCAL_PLAN_COST="step,pass,lane") and the block count on the GPU box; prints the
+# dominant kernel's time for each setting.  Usage: tools/tune_plan.sh  (through gpurun)
+for cost in "4700,21500,65" "4700,30000,65" "4700,15000,65" "3900,21500,65" "5500,21500,65" "4700,21500,120" "4700,21500,30" "3900,28000,100"; do
+  LIFCAL_PLAN_COST=$cost python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-solve 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('cost', '$cost', 'kernel_ms', round(d['roofline']['kernel_ms'],4), 'ms_per_step', round(d['ms_per_step'],4))"
+done
+for nb in 240 252 256 264 272 288 320 384 512; do
+  LIFCAL_V2_BLOCKS=$nb python bench.py --steps 30 --warmup 3 --no-cpu-baseline --no-solve 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('blocks', $nb, 'kernel_ms', round(d['roofline']['kernel_ms'],4), 'ms_per_step', round(d['ms_per_step'],4))"
+done
