@@ -1125,6 +1125,14 @@ __global__ void k_apply_step(Dev d, double t, double* out) {
   }
   if (d.rank == 0) { st2p += st2r; x2p += x2r; }
   st2p = wave_sum(st2p); x2p = wave_sum(x2p);
+  if (d.deterministic) {   // one slot pair per workgroup, waves added in order; k_det_sum adds the workgroups in order
+    __shared__ double part[16][2];
+    const uint32_t wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) { part[wv][0] = st2p; part[wv][1] = x2p; }
+    __syncthreads();
+    if (threadIdx.x < 2) { double t2 = 0.0; for (uint32_t k = 0; k < nwv; ++k) t2 += part[k][threadIdx.x]; d.det_slots[(size_t)blockIdx.x * 2 + threadIdx.x] = t2; }
+    return;
+  }
   if ((threadIdx.x & 63) == 0 && (st2p != 0.0 || x2p != 0.0)) { atomicAdd(out + 0, st2p); atomicAdd(out + 1, x2p); }
 }
 
@@ -1139,6 +1147,14 @@ __global__ void k_dirderiv(Dev d, double* out) {
     if (d.promoted[p] < 0) { const double* g = d.ptacc + (size_t)p * 36 + 6; for (int k = 0; k < 3; ++k) dp += g[k] * d.dP[3 * (size_t)p + k]; }
   }
   dp = wave_sum(dp);
+  if (d.deterministic) {
+    __shared__ double part[16];
+    const uint32_t wv = threadIdx.x >> 6, nwv = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) part[wv] = dp;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t2 = 0.0; for (uint32_t k = 0; k < nwv; ++k) t2 += part[k]; d.det_slots[blockIdx.x] = t2; }
+    return;
+  }
   if ((threadIdx.x & 63) == 0 && dp != 0.0) atomicAdd(out, dp);
 }
 

@@ -409,6 +409,7 @@ int launch_apply_step(lifcal_ba_handle* h, double t) {
   HIP_TRY(hipMemsetAsync(h->ls_buf, 0, 8 * sizeof(double), h->stream));
   const uint32_t n = std::max(std::max(6 * d.F, 17u), std::max(d.n_owned, d.Q));
   hipLaunchKernelGGL(k_apply_step, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, t, h->ls_buf);
+  if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, (n + 255) / 256, 2u, h->ls_buf);
   HIP_TRY(hipGetLastError());
   return 0;
 }
@@ -427,6 +428,7 @@ int eval_trial(lifcal_ba_handle* h, double t, double radius, LsSample* smp) {
   if (!rc) {
     const uint32_t n = std::max(d.n_red, d.n_owned);
     hipLaunchKernelGGL(k_dirderiv, dim3((n + 255) / 256), dim3(256), 0, h->stream, d, h->ls_buf + 2);
+    if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, (n + 255) / 256, 1u, h->ls_buf + 2);
     if (hipGetLastError() != hipSuccess) rc = LIFCAL_BA_ERR_HIP;
   }
   // options.precision = 1: the sweep's cost is that of the fp32 residuals, while phi(0) = x_cost and the candidate costs of the LM
@@ -441,6 +443,7 @@ int eval_trial(lifcal_ba_handle* h, double t, double radius, LsSample* smp) {
 #define CALL_COSTT(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)d.camc, (const double*)d.ft, (const double*)d.lt, pts_eval, h->ls_buf + 3)
       DISPATCH_CFG(h, CALL_COSTT);
 #undef CALL_COSTT
+      if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, grid, 1u, h->ls_buf + 3);
     }
     if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->ls_buf + 3);
     if (hipGetLastError() != hipSuccess) rc = LIFCAL_BA_ERR_HIP;
@@ -764,10 +767,10 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
     if (p->lower && p->lower[k] > -std::numeric_limits<double>::max()) h->constrained = true;
     if (p->upper && p->upper[k] < std::numeric_limits<double>::max()) h->constrained = true;
   }
-  if (opt.deterministic == 1 && (L.n_tiles != 0 || !L.special_owned.empty() || L.use_constraints || h->constrained || !L.use_points)) {
+  if (opt.deterministic == 1 && (L.n_tiles != 0 || !L.special_owned.empty() || L.use_constraints || !L.use_points)) {
     // ordered reductions exist on the LDS-window path only: every point must be a regular point (no distance constraints, no
-    // oversized groups, poses + points refined) and the camera block unbounded (the line search sums with atomics)
-    g_last_error = "options.deterministic = 1 supports the <2,17,6,3> arity without constraints, bounds or oversized groups (every point on the LDS-window path)";
+    // oversized groups, poses + points refined).  Box bounds are fine since round 3: the line search's sums are ordered too.
+    g_last_error = "options.deterministic = 1 supports the <2,17,6,3> arity without constraints or oversized groups (every point on the LDS-window path)";
     return fail(LIFCAL_BA_ERR_INVALID_ARG);
   }
 #define A(ptr, n) do { if (int rc_ = dev_alloc(h, &(ptr), (n))) return fail(rc_); } while (0)
@@ -1284,6 +1287,7 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
 #define CALL_COST2(NR, TAN, ADJ) hipLaunchKernelGGL((k_cost<NR, TAN, ADJ>), dim3(grid), dim3(256), 0, h->stream, d, *ts, (const CamConsts*)d.camc_c, (const double*)d.ft_c, (const double*)d.lt_c, pts_eval, h->partial + 4)
             DISPATCH_CFG(h, CALL_COST2);
 #undef CALL_COST2
+            if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, grid, 1u, h->partial + 4);
           }
           if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
           HIP_TRY(hipGetLastError());

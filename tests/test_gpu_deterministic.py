@@ -71,6 +71,24 @@ def test_the_default_mode_is_the_atomic_one_and_unsupported_structures_are_rejec
     sc2 = scene.make_scene(S(6, 40, None, 0x006, 3111))
     with pytest.raises(LifcalError, match="deterministic"):
         BundleAdjustment(problem(sc2), opts())                      # camera-only arity runs on the global-atomic kernels
-    sc3 = scene.make_scene(S(8, 60, None, 0xF06, 3112, recalib=True))
-    with pytest.raises(LifcalError, match="deterministic"):
-        BundleAdjustment(problem(sc3), opts())                      # box bounds: the line search sums with atomics
+
+
+def test_bounded_problems_are_bitwise_reproducible_through_the_line_search(built):
+    """recalibration pattern (BASELINE configs[4]: slots 0, 2 constant, box bounds) with a box so tight that the projected step fails
+    ceres' Armijo test: the line search's sums (step norms, directional derivative, trial costs) are ordered too since round 3 —
+    three solves agree bitwise and follow the oracle through the same accept / reject sequence"""
+    from tests.helpers import bounded_problem
+    sc = scene.make_scene(S(8, 60, None, 0xF06, 3112, recalib=True, outlier_fraction=0.02))
+    out = []
+    for rep in range(3):
+        pa = bounded_problem(sc)
+        with BundleAdjustment(pa, opts()) as ba:
+            s = ba.performBundleAdjustment()
+        out.append((pa.cam.copy(), pa.views.copy(), pa.pts.copy(), s.final_cost, s.iterations, s.successful_steps, s.unsuccessful_steps))
+    for o in out[1:]:
+        for a, b in zip(o, out[0]):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+    pb = bounded_problem(sc)
+    so = oracle.solve(pb, threads=4)
+    assert (out[0][4], out[0][5], out[0][6]) == (so.iterations, so.successful_steps, so.unsuccessful_steps)
+    assert abs(out[0][3] - so.final_cost) <= 1e-8 * so.final_cost
