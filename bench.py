@@ -381,6 +381,7 @@ def main():
                        "workload": f"{args.workload}: {F_tot} frames, {P_tot} points, {n_obs_total} micro-image observations, "
                                    f"window {spec.window}, config {spec.config:#x} (2 radial + tangential, mlCenterAdj, Cauchy(0.5), refine poses+points)",
                        "obs_per_gpu": n_loc, "n_reduced": n_red, "sharding": "by 3D point" if world > 1 else "single GPU", "comm": comm_used,
+                       "exchange_ms_per_sweep": (prof.ms_exchange if world > 1 else None),
                        "deterministic": bool(args.deterministic)},
             "roofline": {"bound": "hbm", "kernel": "k_sweep (residual+Jacobian+block accumulation)",
                          "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,

@@ -204,6 +204,7 @@ typedef struct lifcal_ba_profile {
                              Jacobian + accumulation + point elimination), or k_front4 start to k_back4 end                */
   double ms_schur;        /* ms_total - ms_accumulate: tables, special points, constraints, exchange, k_finalize, gaps  */
   double ms_total;        /* first kernel of the first sweep to the end of the last one, divided by the sweep count    */
+  double ms_exchange;     /* world_size > 1: pack + collective + unpack of the partial reduced blocks (part of ms_schur)  */
 } lifcal_ba_profile;
 int lifcal_ba_profile_begin(lifcal_ba_handle* h, uint32_t max_sweeps);
 int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out);

@@ -70,7 +70,7 @@ class Info(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("n_sweeps", C.c_uint32), ("special_points", C.c_double), ("ms_accumulate", C.c_double),
-                ("ms_schur", C.c_double), ("ms_total", C.c_double)]
+                ("ms_schur", C.c_double), ("ms_total", C.c_double), ("ms_exchange", C.c_double)]
 
 
 class WindowReport(C.Structure):   # lifcal_ba_window_report

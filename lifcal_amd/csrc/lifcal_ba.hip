@@ -302,7 +302,14 @@ int launch_sweep(lifcal_ba_handle* h, double radius) {
   if (int rc = launch_blocks(h, radius, 0, zeroed)) return rc;
   if (d.use_points && d.n_special) hipLaunchKernelGGL(k_schur, dim3((d.n_special + 3) / 4), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
-  if (int rc = exchange_reduced(h)) return rc;
+  {
+    // multi-rank: the exchange of the partial reduced blocks, bracketed by two records when profiling (world > 1 only: a record is
+    // a barrier packet, and a single-rank sweep has no exchange to time)
+    const bool prof_x = h->prof_active() && (h->opt.world_size > 1 || h->force_exchange);
+    if (prof_x) HIP_TRY(hipEventRecord(h->prof_ev(3), h->stream));
+    if (int rc = exchange_reduced(h)) return rc;
+    if (prof_x) HIP_TRY(hipEventRecord(h->prof_ev(4), h->stream));
+  }
   hipLaunchKernelGGL(k_finalize, dim3((d.n_red + 255) / 256), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
   if (h->prof_active()) {   // ... and closes with the last one (a record per sweep is a barrier packet per sweep)
@@ -1060,11 +1067,12 @@ int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out) {
     hipEvent_t* e = &h->prof_events[(size_t)i * 6];
     HIP_TRY(hipEventElapsedTime(&bms, e[1], e[2]));
     out->ms_accumulate += bms;
+    if (h->opt.world_size > 1 || h->force_exchange) { float xms = 0; if (hipEventElapsedTime(&xms, e[3], e[4]) == hipSuccess) out->ms_exchange += xms; }
   }
   if (n) {
     float t = 0;   // first kernel of the first sweep -> end of the last sweep (includes the gaps between sweeps)
     HIP_TRY(hipEventElapsedTime(&t, h->prof_events[0], h->prof_events[(size_t)(n - 1) * 6 + 5]));
-    out->ms_total = t / n; out->ms_accumulate /= n;
+    out->ms_total = t / n; out->ms_accumulate /= n; out->ms_exchange /= n;
     out->special_points = (double)h->d.n_special;           // (their kernels run outside the dominant kernel's time stamps)
     out->ms_schur = out->ms_total - out->ms_accumulate;     // everything outside the dominant kernel: tables, finalize, special points, exchange, launch gaps
   }
