@@ -64,6 +64,22 @@ def test_solves_are_bitwise_reproducible(built, precision):
         assert np.allclose(out[0][0][:9], pb.cam[:9], rtol=1e-6)
 
 
+def test_ordered_sums_equal_atomic_sums_at_the_widest_window(built):
+    """ADVICE round 2: k_det_reduce finds the blocks covering a frame inside Plan::NF_MAX frames (a constant shared with the planner
+    since round 3, static_assert in lifcal_ba.hip) — a block dropped from the ordered sum would still be bitwise reproducible, so
+    the deterministic system is held against the ATOMIC one (and the oracle) on a scene whose frame windows reach NF_MAX = 20"""
+    sc = scene.make_scene(S(70, 500, 19, 0xF06, 3120, outlier_fraction=0.02))
+    ref = oracle.sweep(problem(sc), radius=1e3, threads=4)
+    with BundleAdjustment(problem(sc), opts(0)) as ba:
+        at = ba.sweep(1e3, want_matrices=True)
+        assert ba.info().max_window_frames >= 19
+    with BundleAdjustment(problem(sc), opts(1)) as ba:
+        dt = ba.sweep(1e3, want_matrices=True)
+    assert abs(dt.cost - at.cost) <= 1e-13 * at.cost
+    assert scaled_max_err(dt.S, at.S) < 1e-11 and vec_err(dt.rhs, at.rhs) < 1e-11 and vec_err(dt.gradient_reduced, at.gradient_reduced) < 1e-11
+    assert scaled_max_err(dt.S, ref.S) < 1e-9 and vec_err(dt.rhs, ref.rhs) < 1e-9
+
+
 def test_the_default_mode_is_the_atomic_one_and_unsupported_structures_are_rejected(built):
     sc = scene.make_scene(S(6, 40, None, 0x506, 3110, n_constraints=3))
     with pytest.raises(LifcalError, match="deterministic"):
