@@ -123,8 +123,10 @@ typedef struct lifcal_ba_options {
   int32_t world_size;           /* number of ranks (1 if single GPU) */
   int32_t verbose;              /* 1: print Ceres-style per-iteration table to stdout (:957) */
   int32_t deterministic;        /* 1: bitwise reproducible results — LDS accumulation in wave order, per-block window slabs summed in block order
-                                   instead of the cross-block f64 atomics, value kernels summed per workgroup in order.  Supported for
-                                   the <2,17,6,3> arity without constraints / bounds / oversized groups; create() rejects the rest.      */
+                                   instead of the cross-block f64 atomics, value kernels summed per workgroup in order; points with distance
+                                   constraints, tracks longer than the LDS window and the camera-only / pose-only arities emit their global
+                                   atomics one wave after the other (slow when every point takes that path).  Every problem structure,
+                                   box bounds included, is supported.                                                                     */
 } lifcal_ba_options;
 
 typedef struct lifcal_ba_summary {

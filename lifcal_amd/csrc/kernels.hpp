@@ -83,6 +83,7 @@ struct Dev {
   // of the value-only kernels (k_det_sum)
   uint32_t deterministic, det_stride;
   double *det_slab, *det_slots;
+  uint32_t* det_turn;            // ... and the turn counters of the global-atomic kernels (special points): [0] k_sweep, [1] k_schur
   const uint32_t* special_owned;
   // constraints
   const uint32_t *c_i, *c_j, *my_cons, *pt_cons0, *pt_cons_list; const double *c_dist, *c_sigma;
@@ -114,6 +115,30 @@ LIFCAL_DEV double wave_sum(double v) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
   return v;
+}
+
+// options.deterministic = 1 on the kernels that sum with GLOBAL atomics (special points: k_sweep, k_schur): the waves emit one
+// after the other, wave `my` after wave `my - 1`, so every accumulator receives its addends in one fixed order (the atomics of one
+// wave reach an address in program order, the lanes of one instruction in the memory pipeline's fixed lane order).  The
+// hand-over is a release / acquire pair at agent scope: the release waits for the wave's own atomics (s_waitcnt vmcnt(0): performed
+// at the coherence point) before the counter moves.  No deadlock for any grid size: a wave waits only for its predecessor,
+// workgroups are dispatched in index order, so the lowest unfinished wave is always resident.  The wait is bounded (4 s of the
+// 100 MHz clock): a protocol error would show up as SCAL_BAD_U — a failed solve — never as a hung GPU.
+LIFCAL_DEV void det_turn_wait(const Dev& d, uint32_t which, uint32_t my) {
+  uint32_t* turn = d.det_turn + which;
+  const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const uint32_t v = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
+    if (v == my) break;
+    __builtin_amdgcn_s_sleep(16);
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 400000000ull) {
+      if ((threadIdx.x & 63u) == 0) atomicAdd(d.scal + SCAL_BAD_U, 1.0);
+      break;
+    }
+  }
+}
+LIFCAL_DEV void det_turn_pass(const Dev& d, uint32_t which, uint32_t my) {
+  if ((threadIdx.x & 63u) == 0) __hip_atomic_store(d.det_turn + which, my + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -198,6 +223,8 @@ __global__ __launch_bounds__(256) void k_sweep(Dev d) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const uint32_t n_waves = gridDim.x * (blockDim.x >> 6);
+  // options.deterministic: one tile per wave (the host sizes the grid), the waves emit in tile order (det_turn_wait / _pass)
+  if (d.deterministic && wave >= d.n_tiles) return;
   const CamConsts c = *d.camc;
   double cc[NCC], gc[NC], cost = 0.0;
 #pragma unroll
@@ -274,6 +301,7 @@ __global__ __launch_bounds__(256) void k_sweep(Dev d) {
       }
     }
 
+    if (d.deterministic) det_turn_wait(d, 0, tile);   // (wave-uniform: a scalar branch, not a lane mask)
     if (cnt > 0 && d.use_poses) {
       const double Am[3][3] = {{A[0], A[1], A[2]}, {A[1], A[3], A[4]}, {A[2], A[4], A[5]}};
       // Gr = [e_x x Y, (0,c0,s0) x Y, R[:,2] x Y]
@@ -377,6 +405,7 @@ __global__ __launch_bounds__(256) void k_sweep(Dev d) {
     const double s = wave_sum(cost);
     if (lane == 63) atomicAdd(d.scal + SCAL_COST, s);
   }
+  if (d.deterministic) det_turn_pass(d, 0, wave);
 }
 
 // one column of the reduced system: ceres LevenbergMarquardtStrategy diagonal (clamp(sigma^2 h) / (radius sigma^2) in the
@@ -413,8 +442,8 @@ namespace lifcal {
 // distance constraints: r = (|Pi - Pj| - dist) / (sigma + 1e-6), squared loss; c_j is always promoted
 // ---------------------------------------------------------------------------------------------
 __global__ void k_constraints(Dev d, int cost_only, const double* pts, double* cost_out) {
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= d.M_local) return;
+  // (options.deterministic: launched as ONE thread, which takes the constraints in order)
+  for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < d.M_local; t += gridDim.x * blockDim.x) {
   const uint32_t c = d.my_cons[t];
   const uint32_t pi = d.c_i[c], pj = d.c_j[c];
   const double* Pi = pts + 3 * (size_t)pi; const double* Pj = pts + 3 * (size_t)pj;
@@ -423,7 +452,7 @@ __global__ void k_constraints(Dev d, int cost_only, const double* pts, double* c
   const double is = 1.0 / (d.c_sigma[c] + 0.000001);
   const double r = (n - d.c_dist[c]) * is;
   atomicAdd(cost_out, 0.5 * r * r);
-  if (cost_only) return;
+  if (cost_only) continue;
   const double in = is / n;
   const double Ji[3] = {dx * in, dy * in, dz * in};  // J_j = -J_i
   const uint32_t F6 = 6 * d.F;
@@ -454,6 +483,7 @@ __global__ void k_constraints(Dev d, int cost_only, const double* pts, double* c
         if (ci > cj) atomicAdd(s_addr(d, ci + a, cj + b), v); else atomicAdd(s_addr(d, cj + b, ci + a), v);
       }
     }
+  }
   }
 }
 
@@ -506,6 +536,7 @@ __global__ __launch_bounds__(256) void k_schur(Dev d, double radius) {
     // U -> diagonal block, g -> gradient, Wc -> camera x point block, Wv -> point x pose blocks
     const uint32_t q = (uint32_t)d.promoted[p], F6 = 6 * d.F, col0 = F6 + 3 * q, camcol = F6 + 3 * d.Q;
     const uint32_t ns = d.pt_nslots[p];
+    if (d.deterministic) det_turn_wait(d, 1, w);
     if (lane < 6) { const int ii[6] = {0, 1, 2, 1, 2, 2}, jj[6] = {0, 0, 0, 1, 1, 2}; s_add(d, col0 + ii[lane], col0 + jj[lane], acc[lane]); }
     if (lane < 3) atomicAdd(d.gB + col0 + lane, acc[6 + lane]);
     for (uint32_t t = lane; t < 3 * d.nc; t += 64) { const uint32_t i = t / d.nc, j = t % d.nc; s_add(d, camcol + j, col0 + i, acc[9 + i * NCMAX + j]); }
@@ -513,6 +544,7 @@ __global__ __launch_bounds__(256) void k_schur(Dev d, double radius) {
       const uint32_t sidx = d.pt_slot0[p] + t / 18, e = t % 18, i = e / 6, j = e % 6;
       s_add(d, col0 + i, 6 * d.gid_fr[sidx] + j, d.Wv[(size_t)sidx * 18 + e]);
     }
+    if (d.deterministic) det_turn_pass(d, 1, w);
     return;
   }
   // damped point block (ceres LevenbergMarquardtStrategy: D^2 = clamp(diag(J^T J)) / radius in scaled space)
@@ -541,6 +573,7 @@ __global__ __launch_bounds__(256) void k_schur(Dev d, double radius) {
     iv[3] = iv[1]; iv[6] = iv[2]; iv[7] = iv[5];
     if (!ok) { for (int k = 0; k < 9; ++k) iv[k] = 0.0; }
   }
+  if (d.deterministic) det_turn_wait(d, 1, w);
   if (lane == 0) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) d.Uinv[9 * (size_t)p + k] = iv[k];
@@ -579,6 +612,7 @@ __global__ __launch_bounds__(256) void k_schur(Dev d, double radius) {
       }
     }
   }
+  if (d.deterministic) det_turn_pass(d, 1, w);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -205,6 +205,7 @@ int exchange_reduced(lifcal_ba_handle* h) {
 uint32_t sweep_grid(const lifcal_ba_handle* h) {
   const uint32_t tiles = h->plan.n_tiles;
   const uint32_t wgs = (tiles + 3) / 4;
+  if (h->d.deterministic) return std::max(1u, wgs);   // one tile per wave: the waves emit in tile order (det_turn_wait)
   return std::max(1u, std::min(wgs, 2048u));
 }
 
@@ -226,6 +227,7 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
   Dev& d = h->d;
   if (!zeroed) HIP_TRY(hipMemsetAsync(h->red_block, 0, h->red_count * sizeof(double), h->stream));
   if (d.n_special) hipLaunchKernelGGL(k_zero_special, dim3((d.n_special * 36 + 255) / 256), dim3(256), 0, h->stream, d);
+  if (d.deterministic && (d.n_tiles || d.n_special)) HIP_TRY(hipMemsetAsync(d.det_turn, 0, 4 * sizeof(uint32_t), h->stream));   // turn counters of k_sweep / k_schur
   // profiling: the dominant kernel carries its own start / stop events (hipExtLaunchKernelGGL: the time stamps are written by the
   // kernel's dispatch packet itself) — event records around it are separate barrier packets, ~2 us of idle queue each, four per sweep
   const bool prof = mode == 0 && h->prof_active();
@@ -269,7 +271,7 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
 #undef CALL_SWEEP
   }
   if (prof && !d.n_blocks) HIP_TRY(hipEventRecord(ev_b, h->stream));
-  if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 0, (const double*)d.pts, d.scal + SCAL_COST);
+  if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3(d.deterministic ? 1 : (d.M_local + 63) / 64), dim3(d.deterministic ? 1 : 64), 0, h->stream, d, 0, (const double*)d.pts, d.scal + SCAL_COST);
   if (d.Q && d.use_points) hipLaunchKernelGGL(k_promote_diag, dim3((d.Q + 63) / 64), dim3(64), 0, h->stream, d);
   HIP_TRY(hipGetLastError());
   return 0;
@@ -379,7 +381,7 @@ int launch_candidate(lifcal_ba_handle* h) {
 #undef CALL_COST
     if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, grid, 1u, h->partial + 4);
   }
-  if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
+  if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3(d.deterministic ? 1 : (d.M_local + 63) / 64), dim3(d.deterministic ? 1 : 64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
   HIP_TRY(hipGetLastError());
   if (int rc = do_allreduce(h, h->partial, 8)) return rc;
   return 0;
@@ -399,7 +401,7 @@ int cost64_current(lifcal_ba_handle* h, double* cost) {
 #undef CALL_COST0
     if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, grid, 1u, h->partial + 4);
   }
-  if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
+  if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3(d.deterministic ? 1 : (d.M_local + 63) / 64), dim3(d.deterministic ? 1 : 64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
   HIP_TRY(hipGetLastError());
   if (int rc = do_allreduce(h, h->partial, 8)) return rc;
   double hp[8];
@@ -452,7 +454,7 @@ int eval_trial(lifcal_ba_handle* h, double t, double radius, LsSample* smp) {
 #undef CALL_COSTT
       if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, grid, 1u, h->ls_buf + 3);
     }
-    if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->ls_buf + 3);
+    if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3(d.deterministic ? 1 : (d.M_local + 63) / 64), dim3(d.deterministic ? 1 : 64), 0, h->stream, d, 1, pts_eval, h->ls_buf + 3);
     if (hipGetLastError() != hipSuccess) rc = LIFCAL_BA_ERR_HIP;
   }
   swap_all();
@@ -774,12 +776,6 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
     if (p->lower && p->lower[k] > -std::numeric_limits<double>::max()) h->constrained = true;
     if (p->upper && p->upper[k] < std::numeric_limits<double>::max()) h->constrained = true;
   }
-  if (opt.deterministic == 1 && (L.n_tiles != 0 || !L.special_owned.empty() || L.use_constraints || !L.use_points)) {
-    // ordered reductions exist on the LDS-window path only: every point must be a regular point (no distance constraints, no
-    // oversized groups, poses + points refined).  Box bounds are fine since round 3: the line search's sums are ordered too.
-    g_last_error = "options.deterministic = 1 supports the <2,17,6,3> arity without constraints or oversized groups (every point on the LDS-window path)";
-    return fail(LIFCAL_BA_ERR_INVALID_ARG);
-  }
 #define A(ptr, n) do { if (int rc_ = dev_alloc(h, &(ptr), (n))) return fail(rc_); } while (0)
 #define U(ptr, vec) do { if (int rc_ = dev_upload(h, &(ptr), (vec))) return fail(rc_); } while (0)
   A(d.cam, 17); A(d.cam_c, 17); A(d.views, 6 * (size_t)d.F); A(d.views_c, 6 * (size_t)d.F); A(d.pts, 3 * (size_t)d.P); A(d.pts_c, 3 * (size_t)d.P);
@@ -819,6 +815,7 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
     d.det_stride = (V2Lds(d.v2_nfmax, true, 256).off_fr + 3u + 1u) & ~1u;
     A(d.det_slab, (size_t)std::max(1u, d.n_blocks) * d.det_stride);
     A(d.det_slots, 4 * (size_t)std::max<uint32_t>(1024u, (std::max(4 * d.n_owned, d.Q) + 255u) / 256u));
+    A(d.det_turn, 4);
   }
   if (d.n_blocks && h->use_sweep4) {
     // k_front4: as many workgroups as the chip holds at once (each walks a contiguous share of one block's tiles)
@@ -1297,7 +1294,7 @@ int lifcal_ba_solve(lifcal_ba_handle* h, lifcal_ba_summary* s) {
 #undef CALL_COST2
             if (d.deterministic) hipLaunchKernelGGL(k_det_sum, dim3(1), dim3(64), 0, h->stream, (const double*)d.det_slots, grid, 1u, h->partial + 4);
           }
-          if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3((d.M_local + 63) / 64), dim3(64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
+          if (d.M_local) hipLaunchKernelGGL(k_constraints, dim3(d.deterministic ? 1 : (d.M_local + 63) / 64), dim3(d.deterministic ? 1 : 64), 0, h->stream, d, 1, pts_eval, h->partial + 4);
           HIP_TRY(hipGetLastError());
           if (int rc = do_allreduce(h, h->partial, 8)) return rc;
           if (int rc = do_allreduce(h, h->ls_buf, 2)) return rc;

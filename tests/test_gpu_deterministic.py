@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from lifcal_amd import BundleAdjustment, LifcalError, _capi as capi, scene
+from lifcal_amd import BundleAdjustment, _capi as capi, scene
 from tests.helpers import S, problem, scaled_max_err, vec_err
 
 pytestmark = pytest.mark.gpu
@@ -80,13 +80,57 @@ def test_ordered_sums_equal_atomic_sums_at_the_widest_window(built):
     assert scaled_max_err(dt.S, ref.S) < 1e-9 and vec_err(dt.rhs, ref.rhs) < 1e-9
 
 
-def test_the_default_mode_is_the_atomic_one_and_unsupported_structures_are_rejected(built):
-    sc = scene.make_scene(S(6, 40, None, 0x506, 3110, n_constraints=3))
-    with pytest.raises(LifcalError, match="deterministic"):
-        BundleAdjustment(problem(sc), opts())                       # distance constraints: special points, global atomics
-    sc2 = scene.make_scene(S(6, 40, None, 0x006, 3111))
-    with pytest.raises(LifcalError, match="deterministic"):
-        BundleAdjustment(problem(sc2), opts())                      # camera-only arity runs on the global-atomic kernels
+SPECIAL_CASES = [
+    ("constraints", S(6, 40, None, 0x506, 3110, n_constraints=3)),
+    ("constraints_adj_robust_windowed", S(24, 300, 6, 0xF06, 3113, n_constraints=12, outlier_fraction=0.03)),   # regular blocks AND special points
+    ("long_tracks", S(30, 400, None, 0xF06, 3114, outlier_fraction=0.02)),   # frame span 30 > NF_MAX: every point on the global-atomic kernels, 190 tiles
+    ("camera_only", S(6, 300, None, 0x006, 3111)),                           # arity <2,17>
+    ("poses_only", S(12, 300, None, 0x306, 3115)),                           # arity <2,17,6>
+]
+
+
+@pytest.mark.parametrize("name,spec", SPECIAL_CASES, ids=[c[0] for c in SPECIAL_CASES])
+def test_special_points_and_arities_are_bitwise_reproducible(built, name, spec):
+    """round 3: the kernels that sum with GLOBAL atomics (k_sweep, k_schur, k_constraints: points with distance constraints, promoted
+    points, tracks longer than the LDS window, the camera-only / pose-only arities) emit in a fixed order in deterministic mode
+    (turn counters, kernels.hpp det_turn_wait): bitwise equal sweeps across repetitions and handles, the atomic mode's values up
+    to summation order, the oracle's at the usual tolerances"""
+    sc = scene.make_scene(spec)
+    ref = oracle.sweep(problem(sc), radius=1e3, threads=4)
+    runs = []
+    for handle in range(2):
+        with BundleAdjustment(problem(sc), opts()) as ba:
+            for rep in range(3):
+                g = ba.sweep(1e3, want_matrices=True)
+                runs.append((g.cost, g.S.copy(), g.rhs.copy(), g.gradient_reduced.copy(), g.point_gradient.copy(), g.point_hessian_inv.copy(), g.gradient_max_norm))
+    c0 = runs[0]
+    for r in runs[1:]:
+        assert r[0] == c0[0] and r[6] == c0[6]
+        for a, b in zip(r[1:6], c0[1:6]):
+            assert np.array_equal(a, b)
+    with BundleAdjustment(problem(sc), opts(0)) as ba:
+        at = ba.sweep(1e3, want_matrices=True)
+    assert abs(c0[0] - at.cost) <= 1e-13 * at.cost
+    assert scaled_max_err(c0[1], at.S) < 1e-11 and vec_err(c0[2], at.rhs) < 1e-11 and vec_err(c0[3], at.gradient_reduced) < 1e-11
+    assert abs(c0[0] - ref.cost) <= 1e-13 * ref.cost
+    assert scaled_max_err(c0[1], ref.S) < 1e-9 and vec_err(c0[2], ref.rhs) < 1e-9
+
+
+@pytest.mark.parametrize("name", ["constraints_adj_robust_windowed", "long_tracks", "poses_only"])
+def test_solves_with_special_points_are_bitwise_reproducible(built, name):
+    sc = scene.make_scene(dict(SPECIAL_CASES)[name])
+    out = []
+    for rep in range(3):
+        pa = problem(sc)
+        with BundleAdjustment(pa, opts()) as ba:
+            s = ba.performBundleAdjustment()
+        out.append((pa.cam.copy(), pa.views.copy(), pa.pts.copy(), s.final_cost, s.iterations, s.successful_steps, s.final_gradient_max_norm))
+    for o in out[1:]:
+        for a, b in zip(o, out[0]):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+    pb = problem(sc)
+    so = oracle.solve(pb, threads=oracle.hardware_threads())
+    assert out[0][4] == so.iterations and abs(out[0][3] - so.final_cost) <= 1e-8 * so.final_cost
 
 
 def test_bounded_problems_are_bitwise_reproducible_through_the_line_search(built):
