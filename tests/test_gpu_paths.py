@@ -170,6 +170,14 @@ def test_huge_group_is_not_truncated(built):
     assert abs(got.cost - ref.cost) <= 1e-12 * ref.cost and scaled_max_err(got.S, ref.S) < 1e-9
 
 
+def ordered():
+    """options.deterministic = 1 for the comparisons of two reduced solvers: the sweeps of both arms then sum in one fixed order, so what
+    the comparison sees is the round-off of the two ELIMINATION orders alone (with atomic sums the arms also differ by the summation
+    order of every sweep, amplified along the gauge directions over ten iterations: the camera assertion failed once in eight runs)"""
+    o = capi.default_options_py(); o.deterministic = 1
+    return o
+
+
 @pytest.mark.parametrize("spec", [S(24, 120, 6, 0xF06, 6101, outlier_fraction=0.02), S(60, 400, 8, 0x506, 6102), S(41, 300, 10, 0xF06, 6103, recalib=True, outlier_fraction=0.02),
                                   S(23, 100, 6, 0xF06, 6104)],
                          ids=["w6_f24", "w8_f60", "w10_f41_recalib", "w6_f23_single_chain_limit"])
@@ -183,7 +191,7 @@ def test_twisted_band_factorisation_equals_the_single_chain(built, monkeypatch, 
     for tw in ("1", "0"):
         monkeypatch.setenv("LIFCAL_TWISTED", tw)
         pa = problem(sc)
-        with BundleAdjustment(pa) as ba:
+        with BundleAdjustment(pa, ordered()) as ba:
             s = ba.performBundleAdjustment()
         res[tw] = (pa, s)
     (p1, s1), (p0, s0) = res["1"], res["0"]
@@ -212,7 +220,7 @@ def test_block_odd_even_reduction_equals_the_chain(built, monkeypatch, spec):
     for cr in ("1", "0"):
         monkeypatch.setenv("LIFCAL_CR", cr)
         pa = problem(sc)
-        with BundleAdjustment(pa) as ba:
+        with BundleAdjustment(pa, ordered()) as ba:
             s = ba.performBundleAdjustment()
         res[cr] = (pa, s)
     (p1, s1), (p0, s0) = res["1"], res["0"]
