@@ -35,7 +35,8 @@ constexpr int ST_GTD = 0, ST_DDD = 1, ST_STEP2 = 2, ST_X2 = 3, ST_CAND_COST = 4,
 
 // device-resident state of the Levenberg-Marquardt loop (k_lm_control; the host mirrors it once per iteration)
 enum { LM_RADIUS = 0, LM_DECREASE = 1, LM_X_COST = 2, LM_GMAX = 3, LM_ITER = 4, LM_INVALID = 5, LM_STEP_OK = 6, LM_SUCCESSFUL = 7, LM_UNSUCCESSFUL = 8,
-       LM_TERMINATION = 9, LM_COMMIT = 10, LM_FRESH = 11, LM_INITIAL_COST = 12, LM_LAST_REL = 13, LM_LAST_STEP = 14, LM_LAST_CHANGE = 15, LM_SWEEPS = 16, LM_N = 24 };
+       LM_TERMINATION = 9, LM_COMMIT = 10, LM_FRESH = 11, LM_INITIAL_COST = 12, LM_LAST_REL = 13, LM_LAST_STEP = 14, LM_LAST_CHANGE = 15, LM_SWEEPS = 16,
+       LM_SEQ = 17 /* round counter of the host mirror */, LM_T0 = 18, LM_TICKS_LINEAR = 19 /* 100 MHz ticks: linear solve + candidate evaluation */, LM_N = 24 };
 struct LmOpts { double f_tol, p_tol, g_tol, min_rel_decrease, max_radius, min_radius; int max_iterations; };
 
 // a set of tiles for the value-only kernels (both sweep paths share them)
@@ -823,6 +824,7 @@ __global__ void k_det_sum(const double* slots, uint32_t n_wg, uint32_t K, double
 // ---------------------------------------------------------------------------------------------
 __global__ void k_finalize(Dev d, double radius) {
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0) d.lm[LM_T0] = (double)__builtin_amdgcn_s_memrealtime();   // the linear solve starts here (k_lm_control reads the span: no event records in the device loop)
   double g = 0.0;
   if (t < d.n_red) g = finalize_column(d, t, radius);
   // max |g| over the reduced block: one atomic per wave (bit pattern of a non-negative double orders like an integer)
@@ -1218,8 +1220,7 @@ __global__ void k_dir_max(Dev d, unsigned long long* slots) {
 // k_lm_commit | next sweep without waiting and reads the state back once per iteration while the next sweep runs.
 // Unbounded problems on one rank (bounds need the host's line search, ranks need rank-consistent host decisions).
 // ---------------------------------------------------------------------------------------------
-__global__ void k_lm_control(Dev d, LmOpts o, const double* partial) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+LIFCAL_DEV void lm_control_step(const Dev& d, const LmOpts& o, const double* partial) {
   double* lm = d.lm;
   lm[LM_COMMIT] = 0.0;
   if (lm[LM_TERMINATION] != 0.0) return;
@@ -1277,6 +1278,18 @@ __global__ void k_lm_control(Dev d, LmOpts o, const double* partial) {
   } else {
     lm[LM_RADIUS] = lm[LM_RADIUS] / lm[LM_DECREASE]; lm[LM_DECREASE] *= 2.0; lm[LM_STEP_OK] = 0.0; lm[LM_UNSUCCESSFUL] += 1.0;
   }
+}
+
+// mirror: the state is copied into MAPPED host memory by the kernel itself and the round number is written last (system-scope
+// fence in between), so the host follows the loop by polling one word — no copy kernel, no event record (each a barrier packet
+// with ~5 us of idle queue) between the kernels of an iteration
+__global__ void k_lm_control(Dev d, LmOpts o, const double* partial, double* mirror, double seq) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  d.lm[LM_TICKS_LINEAR] += (double)__builtin_amdgcn_s_memrealtime() - d.lm[LM_T0];
+  lm_control_step(d, o, partial);
+  for (int i = 0; i < LM_N; ++i) if (i != LM_SEQ) mirror[i] = d.lm[i];
+  __threadfence_system();
+  *(volatile double*)(mirror + LM_SEQ) = seq;
 }
 
 // an accepted candidate becomes the current point (the host loop swaps pointers; device code keeps its arguments and copies)

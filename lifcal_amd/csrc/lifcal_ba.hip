@@ -101,8 +101,8 @@ struct lifcal_ba_handle {
   double* pts_gather = nullptr;
   CamConsts* camc_stats = nullptr;
   double* h_scal = nullptr;      // pinned host mirror
-  double* h_lm = nullptr;        // pinned host mirror of the device-resident LM state (d.lm)
-  hipEvent_t ev_lm = nullptr, ev_la = nullptr, ev_lb = nullptr;
+  double* h_lm = nullptr;        // mapped host mirror of the device-resident LM state (d.lm), written by k_lm_control
+  double* h_lm_dev = nullptr;    // ... its device address
   bool sigma_valid = false;
   bool constrained = false;
   lifcal_ba_allreduce_fn hook = nullptr; void* hook_ctx = nullptr;
@@ -498,13 +498,14 @@ int upload_parameters(lifcal_ba_handle* h) {
       if (p.lower && cam[k] < p.lower[k]) cam[k] = p.lower[k];
       if (p.upper && cam[k] > p.upper[k]) cam[k] = p.upper[k];
     }
+  // (the candidate copies are filled on the device: one trip over PCIe per array)
   HIP_TRY(hipMemcpyAsync(d.cam, cam, sizeof(cam), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipMemcpyAsync(d.cam_c, cam, sizeof(cam), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(hipMemcpyAsync(d.cam_c, d.cam, sizeof(cam), hipMemcpyDeviceToDevice, h->stream));
   if (d.F) { HIP_TRY(hipMemcpyAsync(d.views, p.views, 6 * (size_t)d.F * 8, hipMemcpyHostToDevice, h->stream));
-             HIP_TRY(hipMemcpyAsync(d.views_c, p.views, 6 * (size_t)d.F * 8, hipMemcpyHostToDevice, h->stream)); }
+             HIP_TRY(hipMemcpyAsync(d.views_c, d.views, 6 * (size_t)d.F * 8, hipMemcpyDeviceToDevice, h->stream)); }
   if (d.P) { HIP_TRY(hipMemcpyAsync(d.pts, p.pts, 3 * (size_t)d.P * 8, hipMemcpyHostToDevice, h->stream));
-             HIP_TRY(hipMemcpyAsync(d.pts_c, p.pts, 3 * (size_t)d.P * 8, hipMemcpyHostToDevice, h->stream)); }
-  HIP_TRY(hipStreamSynchronize(h->stream));
+             HIP_TRY(hipMemcpyAsync(d.pts_c, d.pts, 3 * (size_t)d.P * 8, hipMemcpyDeviceToDevice, h->stream)); }
+  HIP_TRY(hipStreamSynchronize(h->stream));   // (cam is a stack array, the caller's arrays may change after the call)
   h->sigma_valid = false;
   return 0;
 }
@@ -944,8 +945,9 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
 #undef U
   cclk.lap("create: alloc + upload");
   if (hipHostMalloc((void**)&h->h_scal, (SCAL_N + 2 * ST_N + 16) * sizeof(double)) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
-  if (hipHostMalloc((void**)&h->h_lm, LM_N * sizeof(double)) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
-  if (hipEventCreate(&h->ev_lm) != hipSuccess || hipEventCreate(&h->ev_la) != hipSuccess || hipEventCreate(&h->ev_lb) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
+  // mapped + coherent: k_lm_control writes the state straight into it, the host polls the round number
+  if (hipHostMalloc((void**)&h->h_lm, 2 * LM_N * sizeof(double), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);   // (second half: staging of the initial state)
+  if (hipHostGetDevicePointer((void**)&h->h_lm_dev, h->h_lm, 0) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
   if (int rc2 = upload_parameters(h)) return fail(rc2);
   cclk.lap("create: parameters");
   *out = h;
@@ -959,7 +961,6 @@ void lifcal_ba_destroy(lifcal_ba_handle* h) {
   for (void* p : h->allocs) (void)hipFree(p);
   if (h->h_scal) (void)hipHostFree(h->h_scal);
   if (h->h_lm) (void)hipHostFree(h->h_lm);
-  for (hipEvent_t e : {h->ev_lm, h->ev_la, h->ev_lb}) if (e) (void)hipEventDestroy(e);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
@@ -1136,39 +1137,49 @@ int lifcal_ba_sweep(lifcal_ba_handle* h, double radius, lifcal_ba_sweep_out* out
 }
 
 // The LM loop with the decisions on the device (k_lm_control / k_lm_commit, kernels.hpp): per iteration the host enqueues
-//   linear solve | candidate + its cost | control | commit | state read-back | the NEXT sweep (at whatever point / radius control chose)
-// and waits for the read-back only — behind it the next sweep is already running, so the queue never drains while the host
-// decides and launches (round 2: two blocking read-backs per iteration, ~250 of ~550 us per iteration were host-induced idle
-// time).  The sweep enqueued behind the terminating decision is the only wasted work.  Unbounded problems on one rank.
+//   linear solve | candidate + its cost | control (writes the state into mapped host memory) | commit | the NEXT sweep (at whatever
+//   point / radius control chose)
+// and polls the round number of the mirrored state — behind it the next sweep is already running, so the queue never drains
+// while the host decides and launches (round 2: two blocking read-backs per iteration, ~250 of ~550 us per iteration were
+// host-induced idle time), and no copy kernel or event record sits between the kernels of an iteration (each a barrier packet:
+// ~5 us of idle queue; the split of the loop's time comes from s_memrealtime stamps taken by the kernels themselves).  The sweep
+// enqueued behind the terminating decision is the only wasted work.  Unbounded problems on one rank.
 static int solve_device_loop(lifcal_ba_handle* h, lifcal_ba_summary* s, double t_start) {
   Dev& d = h->d;
   const lifcal_ba_options& o = h->opt;
   double lm0[LM_N];
   for (int i = 0; i < LM_N; ++i) lm0[i] = 0.0;
   lm0[LM_RADIUS] = o.initial_radius; lm0[LM_DECREASE] = 2.0; lm0[LM_STEP_OK] = 1.0; lm0[LM_FRESH] = 1.0; lm0[LM_INITIAL_COST] = -1.0;
-  std::memcpy(h->h_lm, lm0, sizeof(lm0));
-  HIP_TRY(hipMemcpyAsync(d.lm, h->h_lm, sizeof(lm0), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(hipStreamSynchronize(h->stream));   // (h_lm is reused as the read-back target)
+  std::memcpy(h->h_lm + LM_N, lm0, sizeof(lm0));   // (staging half of the mapped buffer: no synchronisation before the loop starts)
+  HIP_TRY(hipMemcpyAsync(d.lm, h->h_lm + LM_N, sizeof(lm0), hipMemcpyHostToDevice, h->stream));
   const LmOpts lo{o.function_tolerance, o.parameter_tolerance, o.gradient_tolerance, o.min_relative_decrease, o.max_radius, o.min_radius, o.max_iterations};
   double t0 = now_s();
   if (int rc = launch_sweep(h, -1.0)) return rc;
-  float ms_linear = 0.f;
   const uint32_t commit_grid = std::max(1u, std::min(1024u, (3 * d.P + 6 * d.F + 255) / 256));
+  volatile double* mirror = h->h_lm;
+  mirror[LM_SEQ] = 0.0;
   for (int round = 0; round < o.max_iterations + 8; ++round) {
-    HIP_TRY(hipEventRecord(h->ev_la, h->stream));
     if (int rc = launch_linear_solve(h)) return rc;
     if (int rc = launch_candidate(h)) return rc;
-    HIP_TRY(hipEventRecord(h->ev_lb, h->stream));
-    hipLaunchKernelGGL(k_lm_control, dim3(1), dim3(64), 0, h->stream, d, lo, (const double*)h->partial);
+    hipLaunchKernelGGL(k_lm_control, dim3(1), dim3(64), 0, h->stream, d, lo, (const double*)h->partial, h->h_lm_dev, (double)(round + 1));
     hipLaunchKernelGGL(k_lm_commit, dim3(commit_grid), dim3(256), 0, h->stream, d);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(h->h_lm, d.lm, LM_N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipEventRecord(h->ev_lm, h->stream));
     if (int rc = launch_sweep(h, -1.0)) return rc;         // speculative: runs while the host looks at the state
-    HIP_TRY(hipEventSynchronize(h->ev_lm));
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, h->ev_la, h->ev_lb) == hipSuccess) ms_linear += ms;
-    if (h->h_lm[LM_TERMINATION] != 0.0) break;
+    // wait for this round's state: one word of mapped host memory, written last by k_lm_control.  A queue that died would never
+    // write it: every ~2 ms of waiting the stream is asked for its status (an error ends the wait, "not ready" continues it)
+    const double t_wait = now_s();
+    double t_check = t_wait;
+    while (mirror[LM_SEQ] != (double)(round + 1)) {
+      __builtin_ia32_pause();
+      const double t = now_s();
+      if (t - t_check > 2e-3) {
+        t_check = t;
+        const hipError_t q = hipStreamQuery(h->stream);
+        if (q != hipSuccess && q != hipErrorNotReady) { g_last_error = std::string("device LM loop: ") + hipGetErrorString(q); return LIFCAL_BA_ERR_HIP; }
+        if (q == hipSuccess && mirror[LM_SEQ] != (double)(round + 1)) { g_last_error = "device LM loop: the state mirror was not written"; return LIFCAL_BA_ERR_HIP; }
+      }
+    }
+    if (mirror[LM_TERMINATION] != 0.0) break;
   }
   HIP_TRY(hipStreamSynchronize(h->stream));
   const double* lm = h->h_lm;
@@ -1178,7 +1189,7 @@ static int solve_device_loop(lifcal_ba_handle* h, lifcal_ba_summary* s, double t
   s->termination = lm[LM_TERMINATION] != 0.0 ? (int32_t)lm[LM_TERMINATION] : LIFCAL_BA_TERM_MAX_ITERATIONS;
   if (int rc = download_parameters(h)) return rc;
   s->seconds_total = now_s() - t_start;
-  s->seconds_linear_solve = 1e-3 * (double)ms_linear;                      // linear solve + candidate evaluation, by their events
+  s->seconds_linear_solve = 1e-8 * lm[LM_TICKS_LINEAR];                    // linear solve + candidate evaluation: 100 MHz ticks from k_finalize's start to k_lm_control's
   s->seconds_sweep = std::max(0.0, (now_s() - t0) - s->seconds_linear_solve);   // everything else of the loop: sweeps, control, the read-backs
   return 0;
 }

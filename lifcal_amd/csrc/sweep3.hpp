@@ -32,6 +32,8 @@ __global__ __launch_bounds__(128 * WR, 2) void k_sweep3(Dev d, double radius, in
   constexpr uint32_t LP = 64u * WR;    // lanes of a pass (= threads per role)
   constexpr uint32_t NT = 2u * LP;     // threads of the workgroup
   static_assert(HV * LP <= V2Lds::zd_for(LP), "hand-off buffer must fit the Z matrix");
+  // device LM loop (radius < 0: the state lives in HBM): the sweep the host enqueued behind the TERMINATING decision has nothing to do
+  if (radius < 0.0 && d.lm[LM_TERMINATION] != 0.0) return;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const V2Lds lay(d.v2_nfmax, true, LP);
   const uint32_t NFm = lay.nfm, vlen = 6 * NFm + NCMAX + 3;
