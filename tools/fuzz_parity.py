@@ -10,6 +10,7 @@ from tests.helpers import S, problem, scaled_max_err, vec_err     # noqa: E402
 
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
+prec1 = len(sys.argv) > 3 and sys.argv[3] == "precision1"   # options.precision = 1 (fp32 evaluation): its own, wider bars
 bad = 0
 t_start = time.time()
 for case in range(n_cases):
@@ -29,7 +30,7 @@ for case in range(n_cases):
     try:
         sc = scene.make_scene(S(F, P, window, cfg, seed0 + case, **kw))
         ref = oracle.sweep(problem(sc), radius=1e3, threads=8)
-        o = capi.default_options_py(); o.deterministic = det
+        o = capi.default_options_py(); o.deterministic = det; o.precision = 1 if prec1 else 0
         pa = problem(sc)
         with BundleAdjustment(pa, o) as ba:
             got = ba.sweep(1e3, want_matrices=True)
@@ -38,6 +39,8 @@ for case in range(n_cases):
         errs = dict(cost=abs(got.cost - ref.cost) / ref.cost, S=scaled_max_err(got.S, ref.S), rhs=vec_err(got.rhs, ref.rhs),
                     g=vec_err(got.gradient_reduced, ref.gradient_reduced))
         ok = errs["cost"] <= 1e-12 and errs["S"] < 1e-9 and errs["rhs"] < 1e-9 and errs["g"] < 1e-9
+        if prec1:   # tests/test_gpu_precision1.py: cost 2e-6, S 2e-5 block-scaled, gradients 2e-4 (of the terms they cancel from: not checked here)
+            ok = errs["cost"] <= 5e-6 and errs["S"] < 1e-4
         pb = problem(sc)
         so = oracle.solve(pb, threads=8)
         sto = oracle.reproj_stats(pb)
@@ -45,6 +48,8 @@ for case in range(n_cases):
         dc = abs(s.final_cost - so.final_cost) / so.final_cost
         dst = max(abs(st.std_x - sto.std_x), abs(st.std_y - sto.std_y))
         ok2 = traj and dc <= 1e-8 and dst < 1e-7
+        if prec1:   # the fp32 arm may take another path through the last iterations; what it must reach is the same minimum
+            ok2 = dc <= 2e-6 and dst < 1e-4 and abs(s.iterations - so.iterations) <= max(3, so.iterations // 4)
         if not (ok and ok2):
             bad += 1
             print(f"FAIL {tag}: sweep {errs} | solve gpu {(s.iterations, s.successful_steps, s.unsuccessful_steps, s.termination)} oracle "
