@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -752,10 +753,23 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
     g_last_error = "no HIP device available: the bundle-adjustment path has no CPU fallback"; delete h; return LIFCAL_BA_ERR_NO_DEVICE;
   }
   if (hipSetDevice(opt.device) != hipSuccess) { g_last_error = "hipSetDevice failed"; delete h; return LIFCAL_BA_ERR_NO_DEVICE; }
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, opt.device) != hipSuccess) { delete h; return LIFCAL_BA_ERR_NO_DEVICE; }
-  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-    g_last_error = std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code objects only"; delete h; return LIFCAL_BA_ERR_NO_DEVICE;
+  int n_cus = 0;
+  {
+    // the architecture of a device ordinal does not change while the process lives: hipGetDeviceProperties costs ~3 ms per call
+    static std::mutex arch_mutex;
+    static std::string arch_name[64];
+    static int arch_cus[64];
+    std::lock_guard<std::mutex> lock(arch_mutex);
+    std::string& name = arch_name[opt.device & 63];
+    if (name.empty() || opt.device >= 64) {
+      hipDeviceProp_t prop;
+      if (hipGetDeviceProperties(&prop, opt.device) != hipSuccess) { delete h; return LIFCAL_BA_ERR_NO_DEVICE; }
+      name = prop.gcnArchName; arch_cus[opt.device & 63] = prop.multiProcessorCount;
+    }
+    n_cus = arch_cus[opt.device & 63];
+    if (std::strncmp(name.c_str(), "gfx950", 6) != 0) {
+      g_last_error = std::string("device is ") + name + ", this library carries gfx950 code objects only"; delete h; return LIFCAL_BA_ERR_NO_DEVICE;
+    }
   }
   auto fail = [&](int code) { lifcal_ba_destroy(h); return code; };
   if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
@@ -831,7 +845,7 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
 #undef SET_B4
     per_cu = std::max(1, std::min(per_cu, 5));
     if (const char* e = getenv("LIFCAL_F4_PER_CU")) per_cu = std::max(1, atoi(e));
-    const uint32_t capacity = (uint32_t)per_cu * (uint32_t)std::max(1, prop.multiProcessorCount);
+    const uint32_t capacity = (uint32_t)per_cu * (uint32_t)std::max(1, n_cus);
     const uint32_t parts = std::max(1u, capacity / std::max(1u, d.n_blocks));
     std::vector<uint32_t> fwg_blk, fwg_pass0, blk_pt0(L.n_blocks + 1, 0);
     for (uint32_t b = 0; b < L.n_blocks; ++b) {
