@@ -161,6 +161,29 @@ inline void plan_parallel_for(uint32_t n, uint32_t grain, F&& fn) {
 }
 
 // LIFCAL_PLAN_TIMING=1: wall time of each planner phase on stderr
+// n items cut into T contiguous chunks, chunk t worked by thread t: fn(t, begin, end).  Returns T (1: ran inline).  The serial
+// front of the planner (extents, observation sort, lens de-duplication, group runs) uses it with per-chunk partial results that
+// are merged IN CHUNK ORDER, so every array comes out exactly as the one-thread code wrote it (LIFCAL_PLAN_HASH).
+inline unsigned plan_threads() {
+  unsigned hw = std::thread::hardware_concurrency();
+  unsigned T = std::min(8u, hw ? hw : 1u);
+  if (const char* e = getenv("LIFCAL_PLAN_THREADS")) T = (unsigned)std::max(1, atoi(e));
+  return T;
+}
+template <class F>
+inline void plan_parallel_chunks(uint32_t n, unsigned T, F&& fn) {
+  if (T <= 1) { fn(0u, 0u, n); return; }
+  auto span = [&](unsigned t) { return std::pair<uint32_t, uint32_t>((uint32_t)((uint64_t)n * t / T), (uint32_t)((uint64_t)n * (t + 1) / T)); };
+  std::vector<std::thread> pool;
+  std::vector<uint8_t> started(T, 0);
+  for (unsigned t = 1; t < T; ++t) {
+    try { pool.emplace_back([&, t]() { const auto r = span(t); fn(t, r.first, r.second); }); started[t] = 1; } catch (...) { break; }
+  }
+  { const auto r = span(0); fn(0u, r.first, r.second); }
+  for (std::thread& th : pool) th.join();
+  for (unsigned t = 1; t < T; ++t) if (!started[t]) { const auto r = span(t); fn(t, r.first, r.second); }   // (no thread to be had: the caller works the chunk)
+}
+
 struct PlanClock {
   bool on = getenv("LIFCAL_PLAN_TIMING") != nullptr;
   std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
@@ -197,10 +220,33 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   // --- per point: first / last frame, observation count ---
   std::vector<uint32_t> first(L.P, UINT32_MAX), last(L.P, 0), cnt(L.P, 0);
   L.frame_used.assign(L.F, 0); L.point_used.assign(L.P, 0);
-  for (uint32_t i = 0; i < L.N; ++i) {
-    const uint32_t q = p->pt[i], f = p->fr[i];
-    first[q] = std::min(first[q], f); last[q] = std::max(last[q], f); cnt[q]++;
-    L.frame_used[f] = 1; L.point_used[q] = 1;
+  const unsigned TP = (L.N >= (1u << 16)) ? plan_threads() : 1u;   // threads of the chunked phases (small problems: inline)
+  if (TP <= 1) {
+    for (uint32_t i = 0; i < L.N; ++i) {
+      const uint32_t q = p->pt[i], f = p->fr[i];
+      first[q] = std::min(first[q], f); last[q] = std::max(last[q], f); cnt[q]++;
+      L.frame_used[f] = 1; L.point_used[q] = 1;
+    }
+  } else {
+    // per-chunk extents, merged per point (min / max / sum: the order of the chunks does not matter)
+    std::vector<std::vector<uint32_t>> pf(TP), pl(TP), pc(TP);
+    std::vector<std::vector<uint8_t>> fu(TP);
+    plan_parallel_chunks(L.N, TP, [&](unsigned t, uint32_t b, uint32_t e) {
+      pf[t].assign(L.P, UINT32_MAX); pl[t].assign(L.P, 0); pc[t].assign(L.P, 0); fu[t].assign(L.F, 0);
+      uint32_t* f1 = pf[t].data(); uint32_t* l1 = pl[t].data(); uint32_t* c1 = pc[t].data(); uint8_t* u1 = fu[t].data();
+      for (uint32_t i = b; i < e; ++i) {
+        const uint32_t q = p->pt[i], f = p->fr[i];
+        f1[q] = std::min(f1[q], f); l1[q] = std::max(l1[q], f); c1[q]++; u1[f] = 1;
+      }
+    });
+    plan_parallel_chunks(L.P, TP, [&](unsigned, uint32_t b, uint32_t e) {
+      for (uint32_t q = b; q < e; ++q) {
+        uint32_t f0 = UINT32_MAX, l0 = 0, c0 = 0;
+        for (unsigned t = 0; t < TP; ++t) { f0 = std::min(f0, pf[t][q]); l0 = std::max(l0, pl[t][q]); c0 += pc[t][q]; }
+        first[q] = f0; last[q] = l0; cnt[q] = c0; L.point_used[q] = c0 ? 1 : 0;
+      }
+    });
+    for (uint32_t f = 0; f < L.F; ++f) { uint8_t u = 0; for (unsigned t = 0; t < TP; ++t) u |= fu[t][f]; L.frame_used[f] = u; }
   }
   L.bw = 0;
   for (uint32_t q = 0; q < L.P; ++q) if (cnt[q]) L.bw = std::max(L.bw, last[q] - first[q]);
@@ -271,17 +317,40 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   {
     // stable counting sort by the point's rank, then each point's short run by frame (stable: input order breaks ties)
     std::vector<uint32_t> start(L.P + 1, 0);
-    for (uint32_t i = 0; i < L.N; ++i) if (L.owner[p->pt[i]] == rank) ++start[order_rank[p->pt[i]] + 1];
-    for (uint32_t r = 0; r < L.P; ++r) start[r + 1] += start[r];
-    L.obs_order.assign(start[L.P], 0);
-    std::vector<uint32_t> fill(start.begin(), start.end() - 1);
-    for (uint32_t i = 0; i < L.N; ++i) if (L.owner[p->pt[i]] == rank) L.obs_order[fill[order_rank[p->pt[i]]]++] = i;
-    for (uint32_t r = 0; r < L.P; ++r) {
-      uint32_t* b = L.obs_order.data() + start[r]; uint32_t* e = L.obs_order.data() + start[r + 1];
-      bool sorted = true;
-      for (uint32_t* q = b; q + 1 < e; ++q) if (p->fr[q[1]] < p->fr[q[0]]) { sorted = false; break; }
-      if (!sorted) std::stable_sort(b, e, [&](uint32_t a, uint32_t c) { return p->fr[a] < p->fr[c]; });
+    if (TP <= 1) {
+      for (uint32_t i = 0; i < L.N; ++i) if (L.owner[p->pt[i]] == rank) ++start[order_rank[p->pt[i]] + 1];
+      for (uint32_t r = 0; r < L.P; ++r) start[r + 1] += start[r];
+      L.obs_order.assign(start[L.P], 0);
+      std::vector<uint32_t> fill(start.begin(), start.end() - 1);
+      for (uint32_t i = 0; i < L.N; ++i) if (L.owner[p->pt[i]] == rank) L.obs_order[fill[order_rank[p->pt[i]]]++] = i;
+    } else {
+      // the same stable counting sort with per-chunk histograms: chunk t's observations of a point go behind those of the chunks
+      // before it, in input order inside the chunk
+      std::vector<std::vector<uint32_t>> hist(TP);
+      plan_parallel_chunks(L.N, TP, [&](unsigned t, uint32_t b, uint32_t e) {
+        hist[t].assign(L.P, 0);
+        uint32_t* h = hist[t].data();
+        for (uint32_t i = b; i < e; ++i) if (L.owner[p->pt[i]] == rank) ++h[order_rank[p->pt[i]]];
+      });
+      for (uint32_t r = 0; r < L.P; ++r) {
+        uint32_t at = start[r];
+        for (unsigned t = 0; t < TP; ++t) { const uint32_t c = hist[t][r]; hist[t][r] = at; at += c; }   // histogram -> first slot of the chunk's run
+        start[r + 1] = at;
+      }
+      L.obs_order.assign(start[L.P], 0);
+      plan_parallel_chunks(L.N, TP, [&](unsigned t, uint32_t b, uint32_t e) {
+        uint32_t* fill = hist[t].data();
+        for (uint32_t i = b; i < e; ++i) if (L.owner[p->pt[i]] == rank) L.obs_order[fill[order_rank[p->pt[i]]]++] = i;
+      });
     }
+    plan_parallel_chunks(L.P, TP, [&](unsigned, uint32_t rb, uint32_t re) {
+      for (uint32_t r = rb; r < re; ++r) {
+        uint32_t* b = L.obs_order.data() + start[r]; uint32_t* e = L.obs_order.data() + start[r + 1];
+        bool sorted = true;
+        for (uint32_t* q = b; q + 1 < e; ++q) if (p->fr[q[1]] < p->fr[q[0]]) { sorted = false; break; }
+        if (!sorted) std::stable_sort(b, e, [&](uint32_t a, uint32_t c) { return p->fr[a] < p->fr[c]; });
+      }
+    });
   }
   L.n_obs_local = (uint32_t)L.obs_order.size();
 
@@ -296,35 +365,66 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
     }
   };
   // open-addressing table (linear probing, load <= 1/2, doubles when full): ids in order of first appearance
-  std::vector<uint32_t> obs_lens(L.n_obs_local);
-  L.lens_xy.clear();
-  {
-    size_t cap = 1 << 15;
-    std::vector<uint32_t> table(cap, UINT32_MAX);
-    KeyHash hash;
-    auto key_of = [&](uint32_t id) { Key k; std::memcpy(&k.a, &L.lens_xy[2 * (size_t)id], 8); std::memcpy(&k.b, &L.lens_xy[2 * (size_t)id + 1], 8); return k; };
-    auto grow = [&]() {
+  struct LensTable {
+    std::vector<double> xy; std::vector<uint32_t> table; size_t cap = 0;
+    explicit LensTable(size_t c0 = 1 << 15) : table(c0, UINT32_MAX), cap(c0) {}
+    Key key_of(uint32_t id) const { Key k; std::memcpy(&k.a, &xy[2 * (size_t)id], 8); std::memcpy(&k.b, &xy[2 * (size_t)id + 1], 8); return k; }
+    void grow() {
       cap *= 2;
       table.assign(cap, UINT32_MAX);
-      for (uint32_t id = 0; id < (uint32_t)(L.lens_xy.size() / 2); ++id) {
+      KeyHash hash;
+      for (uint32_t id = 0; id < (uint32_t)(xy.size() / 2); ++id) {
         size_t at = hash(key_of(id)) & (cap - 1);
         while (table[at] != UINT32_MAX) at = (at + 1) & (cap - 1);
         table[at] = id;
       }
-    };
-    for (uint32_t s = 0; s < L.n_obs_local; ++s) {
-      const uint32_t i = L.obs_order[s];
-      Key k; std::memcpy(&k.a, &p->mcx[i], 8); std::memcpy(&k.b, &p->mcy[i], 8);
+    }
+    uint32_t find_or_insert(double x, double y) {
+      Key k; std::memcpy(&k.a, &x, 8); std::memcpy(&k.b, &y, 8);
+      KeyHash hash;
       size_t at = hash(k) & (cap - 1);
       uint32_t id;
       while ((id = table[at]) != UINT32_MAX && !(key_of(id) == k)) at = (at + 1) & (cap - 1);
       if (id == UINT32_MAX) {
-        id = (uint32_t)(L.lens_xy.size() / 2);
+        id = (uint32_t)(xy.size() / 2);
         table[at] = id;
-        L.lens_xy.push_back(p->mcx[i]); L.lens_xy.push_back(p->mcy[i]);
+        xy.push_back(x); xy.push_back(y);
         if ((size_t)(id + 1) * 2 > cap) grow();
       }
-      obs_lens[s] = id;
+      return id;
+    }
+  };
+  std::vector<uint32_t> obs_lens(L.n_obs_local);
+  L.lens_xy.clear();
+  {
+    // chunk t numbers the lenses of its stretch of the sorted observations in order of first appearance; the chunks' lists are
+    // then entered into ONE table in chunk order — the global order of first appearance, as a single pass would number them —
+    // and the observations' local ids are translated
+    const unsigned TL = (L.n_obs_local >= (1u << 16)) ? TP : 1u;
+    std::vector<LensTable> local;
+    local.reserve(TL);
+    for (unsigned t = 0; t < TL; ++t) local.emplace_back(TL > 1 ? (size_t)1 << 13 : (size_t)1 << 15);
+    std::vector<std::pair<uint32_t, uint32_t>> span(TL);
+    plan_parallel_chunks(L.n_obs_local, TL, [&](unsigned t, uint32_t b, uint32_t e) {
+      span[t] = {b, e};
+      LensTable& lt = local[t];
+      for (uint32_t sidx = b; sidx < e; ++sidx) { const uint32_t i = L.obs_order[sidx]; obs_lens[sidx] = lt.find_or_insert(p->mcx[i], p->mcy[i]); }
+    });
+    if (TL <= 1) {
+      L.lens_xy.swap(local[0].xy);
+    } else {
+      LensTable global;
+      std::vector<std::vector<uint32_t>> remap(TL);
+      for (unsigned t = 0; t < TL; ++t) {
+        const uint32_t nl = (uint32_t)(local[t].xy.size() / 2);
+        remap[t].resize(nl);
+        for (uint32_t id = 0; id < nl; ++id) remap[t][id] = global.find_or_insert(local[t].xy[2 * (size_t)id], local[t].xy[2 * (size_t)id + 1]);
+      }
+      plan_parallel_chunks(TL, TL, [&](unsigned t, uint32_t, uint32_t) {
+        const uint32_t* m = remap[t].data();
+        for (uint32_t sidx = span[t].first; sidx < span[t].second; ++sidx) obs_lens[sidx] = m[obs_lens[sidx]];
+      });
+      L.lens_xy.swap(global.xy);
     }
   }
   L.n_lenses = (uint32_t)(L.lens_xy.size() / 2);
@@ -333,12 +433,34 @@ inline int build_plan(const lifcal_ba_problem* p, int rank, int world, Plan* pl,
   // --- groups (runs of equal (point, frame)), gid numbering ---
   struct Group { uint32_t pt, fr, s0, n; };
   std::vector<Group> groups;
-  for (uint32_t s = 0; s < L.n_obs_local;) {
-    const uint32_t i = L.obs_order[s];
-    uint32_t e = s + 1;
-    while (e < L.n_obs_local && p->pt[L.obs_order[e]] == p->pt[i] && p->fr[L.obs_order[e]] == p->fr[i]) ++e;
-    groups.push_back({p->pt[i], p->fr[i], s, e - s});
-    s = e;
+  {
+    // run starts per chunk (an observation whose (point, frame) differs from its predecessor's), concatenated in chunk order
+    const unsigned TG = (L.n_obs_local >= (1u << 16)) ? TP : 1u;
+    std::vector<std::vector<uint32_t>> heads(TG);
+    plan_parallel_chunks(L.n_obs_local, TG, [&](unsigned t, uint32_t b, uint32_t e) {
+      std::vector<uint32_t>& h = heads[t];
+      h.reserve((e - b) / 3 + 16);
+      for (uint32_t sidx = b; sidx < e; ++sidx) {
+        const uint32_t i = L.obs_order[sidx];
+        if (sidx == 0) { h.push_back(0); continue; }
+        const uint32_t j = L.obs_order[sidx - 1];
+        if (p->pt[j] != p->pt[i] || p->fr[j] != p->fr[i]) h.push_back(sidx);
+      }
+    });
+    std::vector<uint32_t> off(TG + 1, 0);
+    for (unsigned t = 0; t < TG; ++t) off[t + 1] = off[t] + (uint32_t)heads[t].size();
+    groups.resize(off[TG]);
+    plan_parallel_chunks(TG, TG, [&](unsigned t, uint32_t, uint32_t) {
+      const std::vector<uint32_t>& h = heads[t];
+      for (size_t k = 0; k < h.size(); ++k) {
+        const uint32_t s0 = h[k];
+        uint32_t next;   // the next run's start: in this chunk, in the next non-empty chunk, or the end
+        if (k + 1 < h.size()) next = h[k + 1];
+        else { next = L.n_obs_local; for (unsigned u = t + 1; u < TG; ++u) if (!heads[u].empty()) { next = heads[u][0]; break; } }
+        const uint32_t i = L.obs_order[s0];
+        groups[off[t] + k] = Group{p->pt[i], p->fr[i], s0, next - s0};
+      }
+    });
   }
   L.n_groups = (uint32_t)groups.size();
   L.gid_fr.resize(L.n_groups);
