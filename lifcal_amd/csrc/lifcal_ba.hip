@@ -40,6 +40,27 @@ namespace {
 
 thread_local std::string g_last_error;
 
+// Streams of destroyed handles are kept for the next create on the same device (a stream costs ~4 ms to make: the frame-windowed
+// driver creates one handle per window).  A handle returns its stream idle (lifcal_ba_destroy synchronises first).
+static std::mutex g_stream_pool_mutex;
+static std::vector<hipStream_t> g_stream_pool[64];
+static hipStream_t stream_pool_take(int device) {
+  if (device < 0 || device >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+  std::vector<hipStream_t>& v = g_stream_pool[device];
+  if (v.empty()) return nullptr;
+  hipStream_t s = v.back(); v.pop_back();
+  return s;
+}
+static bool stream_pool_give(int device, hipStream_t s) {
+  if (device < 0 || device >= 64) return false;
+  std::lock_guard<std::mutex> lock(g_stream_pool_mutex);
+  std::vector<hipStream_t>& v = g_stream_pool[device];
+  if (v.size() >= 8) return false;
+  v.push_back(s);
+  return true;
+}
+
 #define HIP_TRY(expr)                                                                         \
   do {                                                                                        \
     hipError_t e_ = (expr);                                                                   \
@@ -772,7 +793,8 @@ static int create_impl(const lifcal_ba_problem* p, const lifcal_ba_options* o, l
     }
   }
   auto fail = [&](int code) { lifcal_ba_destroy(h); return code; };
-  if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
+  if ((h->stream = stream_pool_take(opt.device)) == nullptr &&
+      hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
   if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return fail(LIFCAL_BA_ERR_HIP);
   cclk.lap("create: device, stream");
 
@@ -978,7 +1000,7 @@ void lifcal_ba_destroy(lifcal_ba_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
-  if (h->stream) (void)hipStreamDestroy(h->stream);
+  if (h->stream && !stream_pool_give(h->opt.device, h->stream)) (void)hipStreamDestroy(h->stream);
   delete h;
 }
 
