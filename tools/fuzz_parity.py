@@ -11,6 +11,7 @@ from tests.helpers import S, problem, scaled_max_err, vec_err     # noqa: E402
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 7000
 prec1 = len(sys.argv) > 3 and sys.argv[3] == "precision1"   # options.precision = 1 (fp32 evaluation): its own, wider bars
+big = len(sys.argv) > 3 and sys.argv[3] == "big"             # long sequences: 100-400 frames, 500-4000 points (the block odd-even reduction, many blocks)
 bad = 0
 t_start = time.time()
 for case in range(n_cases):
@@ -18,6 +19,8 @@ for case in range(n_cases):
     F = int(rng.integers(3, 70))
     P = int(rng.integers(20, 420))
     window = None if rng.random() < 0.3 else int(rng.integers(2, min(F, 26) + 1))
+    if big:
+        F = int(rng.integers(100, 400)); P = int(rng.integers(500, 4000)); window = int(rng.integers(2, 13))
     nr = int(rng.integers(0, 3)); tan = int(rng.integers(0, 2))
     arity = [0x000, 0x100, 0x400, 0x500, 0x500, 0x500][int(rng.integers(0, 6))]
     cfg = nr | (tan << 2) | arity | (0x200 if rng.random() < 0.5 else 0) | (0x800 if rng.random() < 0.5 else 0)
