@@ -207,8 +207,13 @@ typedef struct lifcal_ba_profile {
   double ms_schur;        /* ms_total - ms_accumulate: tables, special points, constraints, exchange, k_finalize, gaps  */
   double ms_total;        /* first kernel of the first sweep to the end of the last one, divided by the sweep count    */
   double ms_exchange;     /* world_size > 1: pack + collective + unpack of the partial reduced blocks (part of ms_schur)  */
+  uint32_t n_sampled;     /* sweeps of the span whose dominant kernel carried the time stamps (ms_accumulate / ms_exchange average THESE) */
 } lifcal_ba_profile;
+/* The next max_sweeps sweeps form a span (ms_total: two event records, before the first and behind the last).  A SAMPLED sweep's
+ * dominant kernel carries its own start / stop events, which costs ~5 us of queue time per sampled sweep: _begin samples every
+ * sweep, _begin_sampled every stride-th (0, stride, 2 stride, ...) so that a timing loop is measured nearly undisturbed.            */
 int lifcal_ba_profile_begin(lifcal_ba_handle* h, uint32_t max_sweeps);
+int lifcal_ba_profile_begin_sampled(lifcal_ba_handle* h, uint32_t max_sweeps, uint32_t stride);
 int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out);
 
 /* replaces reference :1026-1103 (evaluated on the device-resident parameters) */

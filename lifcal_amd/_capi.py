@@ -70,7 +70,7 @@ class Info(C.Structure):
 
 class Profile(C.Structure):
     _fields_ = [("n_sweeps", C.c_uint32), ("special_points", C.c_double), ("ms_accumulate", C.c_double),
-                ("ms_schur", C.c_double), ("ms_total", C.c_double), ("ms_exchange", C.c_double)]
+                ("ms_schur", C.c_double), ("ms_total", C.c_double), ("ms_exchange", C.c_double), ("n_sampled", C.c_uint32)]
 
 
 class WindowReport(C.Structure):   # lifcal_ba_window_report
@@ -215,6 +215,7 @@ PROTOTYPES = {
     "lifcal_ba_sweep": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(SweepOut)]),
     "lifcal_ba_sweep_enqueue": (C.c_int, [C.c_void_p, C.c_double]),
     "lifcal_ba_profile_begin": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "lifcal_ba_profile_begin_sampled": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32]),
     "lifcal_ba_profile_end": (C.c_int, [C.c_void_p, C.POINTER(Profile)]),
     "lifcal_ba_reproj_stats": (C.c_int, [C.c_void_p, C.c_double, C.POINTER(Stats)]),
     "lifcal_ba_project_observations": (C.c_int, [C.c_void_p, dptr, dptr]),

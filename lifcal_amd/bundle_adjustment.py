@@ -135,8 +135,10 @@ class BundleAdjustment:
         if rc:
             _check(self.lib, rc, "lifcal_ba_sweep_enqueue")
 
-    def profile_begin(self, max_sweeps: int):
-        _check(self.lib, self.lib.lifcal_ba_profile_begin(self._h, int(max_sweeps)), "lifcal_ba_profile_begin")
+    def profile_begin(self, max_sweeps: int, stride: int = 1):
+        """The next max_sweeps sweeps form a profiled span; every stride-th one carries the dominant kernel's own time stamps
+        (a stamped launch costs ~5 us of queue time: timing loops sample, lifcal_ba_profile_begin_sampled)."""
+        _check(self.lib, self.lib.lifcal_ba_profile_begin_sampled(self._h, int(max_sweeps), int(stride)), "lifcal_ba_profile_begin_sampled")
 
     def profile_end(self) -> capi.Profile:
         p = capi.Profile()

@@ -141,9 +141,14 @@ struct lifcal_ba_handle {
   CrPlan cr; bool use_cr = false;   // block odd-even reduction (bandchol3.hpp): long sequences
   bool twisted = false; uint32_t tw_m = 0; double *dumpA = nullptr, *dumpB = nullptr;   // two-ended factorisation (bandchol2.hpp): frames [0, tw_m) | bw middle frames | the rest
   // profiling: 5 events per sweep (start, after tables, after k_sweep, before k_schur, after k_schur, end)
-  std::vector<hipEvent_t> prof_events; uint32_t prof_cap = 0, prof_used = 0; bool prof_on = false, prof_closed = false;
+  // A profile spans prof_cap sweeps (two records: before the first, behind the last); every prof_stride-th sweep of the span is
+  // SAMPLED: its dominant kernel carries its own start / stop events — which costs ~5 us of queue time per sampled sweep, so a
+  // timing loop samples a few of its sweeps rather than all of them (lifcal_ba_profile_begin_sampled)
+  std::vector<hipEvent_t> prof_events; uint32_t prof_cap = 0, prof_used = 0, prof_seen = 0, prof_stride = 1; bool prof_on = false, prof_closed = false;
+  hipEvent_t prof_span0 = nullptr, prof_span1 = nullptr;
   hipEvent_t prof_ev(int which) { return prof_events[(size_t)prof_used * 6 + which]; }
-  bool prof_active() const { return prof_on && prof_used < prof_cap; }
+  bool prof_in_span() const { return prof_on && prof_seen < prof_cap; }
+  bool prof_active() const { return prof_in_span() && prof_seen % prof_stride == 0; }
 };
 
 namespace {
@@ -302,7 +307,7 @@ int launch_blocks(lifcal_ba_handle* h, double radius, int mode, bool zeroed) {
 // one Jacobian + Schur sweep at the current point and the given trust-region radius
 int launch_sweep(lifcal_ba_handle* h, double radius) {
   Dev& d = h->d;
-  if (h->prof_active() && h->prof_used == 0) HIP_TRY(hipEventRecord(h->prof_ev(0), h->stream));   // the span opens with the first profiled sweep ...
+  if (h->prof_in_span() && h->prof_seen == 0) HIP_TRY(hipEventRecord(h->prof_span0, h->stream));   // the span opens with the first profiled sweep ...
   // the table kernel also zero-fills the reduced block and the step scalars
   if (int rc = launch_tables(h, d.cam, d.views, d.camc, d.ft, d.lt, true, true, h->red_block, h->red_count, d.step, ST_N, d.ltf)) return rc;
   bool zeroed = true;
@@ -336,9 +341,10 @@ int launch_sweep(lifcal_ba_handle* h, double radius) {
   }
   hipLaunchKernelGGL(k_finalize, dim3((d.n_red + 255) / 256), dim3(256), 0, h->stream, d, radius);
   HIP_TRY(hipGetLastError());
-  if (h->prof_active()) {   // ... and closes with the last one (a record per sweep is a barrier packet per sweep)
-    if (h->prof_used + 1 == h->prof_cap) { HIP_TRY(hipEventRecord(h->prof_ev(5), h->stream)); h->prof_closed = true; }
-    h->prof_used++;
+  if (h->prof_in_span()) {   // ... and closes with the last one (a record per sweep is a barrier packet per sweep)
+    if (h->prof_seen + 1 == h->prof_cap) { HIP_TRY(hipEventRecord(h->prof_span1, h->stream)); h->prof_closed = true; }
+    if (h->prof_active()) h->prof_used++;
+    h->prof_seen++;
   }
   return 0;
 }
@@ -1000,6 +1006,7 @@ void lifcal_ba_destroy(lifcal_ba_handle* h) {
   if (h->ev0) (void)hipEventDestroy(h->ev0);
   if (h->ev1) (void)hipEventDestroy(h->ev1);
   for (hipEvent_t e : h->prof_events) (void)hipEventDestroy(e);
+  if (h->prof_span0) { (void)hipEventDestroy(h->prof_span0); (void)hipEventDestroy(h->prof_span1); }
   if (h->stream && !stream_pool_give(h->opt.device, h->stream)) (void)hipStreamDestroy(h->stream);
   delete h;
 }
@@ -1082,35 +1089,40 @@ int lifcal_ba_sweep_enqueue(lifcal_ba_handle* h, double radius) {
   return launch_sweep(h, radius);
 }
 
-int lifcal_ba_profile_begin(lifcal_ba_handle* h, uint32_t max_sweeps) {
-  if (!h) return LIFCAL_BA_ERR_INVALID_ARG;
+int lifcal_ba_profile_begin_sampled(lifcal_ba_handle* h, uint32_t max_sweeps, uint32_t stride) {
+  if (!h || stride == 0) return LIFCAL_BA_ERR_INVALID_ARG;
   HIP_TRY(hipSetDevice(h->opt.device));
-  while (h->prof_events.size() < (size_t)max_sweeps * 6) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->prof_events.push_back(e); }
-  h->prof_cap = max_sweeps; h->prof_used = 0; h->prof_on = true; h->prof_closed = false;
+  const size_t samples = ((size_t)max_sweeps + stride - 1) / stride;
+  while (h->prof_events.size() < samples * 6) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); h->prof_events.push_back(e); }
+  if (!h->prof_span0) { HIP_TRY(hipEventCreate(&h->prof_span0)); HIP_TRY(hipEventCreate(&h->prof_span1)); }
+  h->prof_cap = max_sweeps; h->prof_used = 0; h->prof_seen = 0; h->prof_stride = stride; h->prof_on = true; h->prof_closed = false;
   return 0;
 }
+int lifcal_ba_profile_begin(lifcal_ba_handle* h, uint32_t max_sweeps) { return lifcal_ba_profile_begin_sampled(h, max_sweeps, 1u); }
 
 int lifcal_ba_profile_end(lifcal_ba_handle* h, lifcal_ba_profile* out) {
   if (!h || !out) return LIFCAL_BA_ERR_INVALID_ARG;
-  const uint32_t n = h->prof_used;
-  if (n && !h->prof_closed) HIP_TRY(hipEventRecord(h->prof_events[(size_t)(n - 1) * 6 + 5], h->stream));   // fewer sweeps than reserved: close the span now
+  const uint32_t n = h->prof_used, seen = h->prof_seen;
+  if (seen && !h->prof_closed) HIP_TRY(hipEventRecord(h->prof_span1, h->stream));   // fewer sweeps than reserved: close the span now
   HIP_TRY(hipStreamSynchronize(h->stream));
   std::memset(out, 0, sizeof(*out));
-  for (uint32_t i = 0; i < n; ++i) {   // per sweep: the dominant kernel's own start / stop stamps (events 1, 2)
+  for (uint32_t i = 0; i < n; ++i) {   // per sampled sweep: the dominant kernel's own start / stop stamps (events 1, 2)
     float bms = 0;
     hipEvent_t* e = &h->prof_events[(size_t)i * 6];
     HIP_TRY(hipEventElapsedTime(&bms, e[1], e[2]));
     out->ms_accumulate += bms;
     if (h->opt.world_size > 1 || h->force_exchange) { float xms = 0; if (hipEventElapsedTime(&xms, e[3], e[4]) == hipSuccess) out->ms_exchange += xms; }
   }
-  if (n) {
-    float t = 0;   // first kernel of the first sweep -> end of the last sweep (includes the gaps between sweeps)
-    HIP_TRY(hipEventElapsedTime(&t, h->prof_events[0], h->prof_events[(size_t)(n - 1) * 6 + 5]));
-    out->ms_total = t / n; out->ms_accumulate /= n; out->ms_exchange /= n;
+  if (seen) {
+    float t = 0;   // first kernel of the first sweep -> end of the last sweep of the span (includes the gaps between sweeps)
+    HIP_TRY(hipEventElapsedTime(&t, h->prof_span0, h->prof_span1));
+    out->ms_total = t / seen;
+    if (n) { out->ms_accumulate /= n; out->ms_exchange /= n; }
     out->special_points = (double)h->d.n_special;           // (their kernels run outside the dominant kernel's time stamps)
     out->ms_schur = out->ms_total - out->ms_accumulate;     // everything outside the dominant kernel: tables, finalize, special points, exchange, launch gaps
   }
-  out->n_sweeps = n;
+  out->n_sweeps = seen;
+  out->n_sampled = n;
   h->prof_on = false;
   return 0;
 }

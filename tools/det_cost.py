@@ -21,7 +21,7 @@ for name, spec in CASES + SPECIAL_CASES + extra:
                 g = ba.sweep(1e3, want_matrices=True)
                 outs.append((g.S.copy(), g.rhs.copy()))
             differing = sum(1 for a in outs[1:] if not (np.array_equal(a[0], outs[0][0]) and np.array_equal(a[1], outs[0][1])))
-            ba.profile_begin(20)
+            ba.profile_begin(20, 1)
             for rep in range(20):
                 ba.sweep_enqueue(1e3)
             pr = ba.profile_end()   # (synchronises)
