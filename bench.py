@@ -318,11 +318,21 @@ def main():
         torch.cuda.synchronize()
 
     first = ba.sweep(radius)                       # also fixes the Jacobi scaling (iteration-0 semantics)
-    t_heat = time.perf_counter()
-    while (time.perf_counter() - t_heat) * 1e3 < args.preheat_ms:   # clocks up (see --preheat-ms); the same work as the timed steps, untimed
-        for _ in range(50):
-            ba.sweep_enqueue(radius)
-        ba.sweep(radius)
+    if args.preheat_ms > 0:   # clocks up (see --preheat-ms); the same work as the timed steps, untimed
+        def heat_batch():
+            for _ in range(50):
+                ba.sweep_enqueue(radius)
+            ba.sweep(radius)
+        t_heat = time.perf_counter()
+        heat_batch()
+        batch_ms = max(1e-3, (time.perf_counter() - t_heat) * 1e3)
+        rounds = max(0, int(args.preheat_ms / batch_ms + 0.999) - 1)
+        if dist is not None:   # every sweep holds a collective: the ranks must run the SAME number of them
+            t = torch.tensor([rounds], dtype=torch.int64, device="cpu" if args.comm == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rounds = int(t.item())
+        for _ in range(min(rounds, 200)):
+            heat_batch()
     for _ in range(args.warmup):
         ba.sweep_enqueue(radius)
     ba.sweep(radius)
